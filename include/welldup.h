@@ -1,0 +1,192 @@
+/*
+ * welldup.h - C ABI of libwelldup.so, the MI355X (gfx950) well-duplicate scanner.
+ *
+ * The reference (EdinburghGenomics/well_duplicates) has no plugin or FFI interface: the
+ * scan path is inline Python.  This ABI is cut at the seams a replacement has to honour
+ * (SURVEY.md section 8b); each entry point cites the reference code it stands in for
+ * (paths relative to /root/reference).  INTEGRATION.md shows the ctypes binding a
+ * maintainer of the reference would add to count_well_duplicates.py.
+ *
+ * Conventions
+ *   - plain C: opaque context, plain pointers and sizes, caller-allocated outputs.
+ *   - every function returns WD_OK (0) or a negative WD_ERR_* code; wd_strerror() names the
+ *     code, wd_last_error() gives the detail (e.g. the HIP error string) for that context.
+ *   - one context per GPU; a context is thread-compatible (no hidden globals), not
+ *     thread-safe: serialise calls on one context.
+ *   - "device pointer" = address valid on the context's GPU (hipMalloc, a torch tensor's
+ *     data_ptr(), or wd_malloc below).  "host pointer" = ordinary process memory.
+ *   - error codes map back to the reference's exception classes:
+ *       WD_ERR_INDEX        -> IndexError       (bcl_direct_reader.py:186-192)
+ *       WD_ERR_EMPTY_LEVEL  -> AssertionError   (count_well_duplicates.py:249)
+ *       WD_ERR_ARG          -> ValueError
+ *       everything else     -> RuntimeError
+ */
+#ifndef WELLDUP_H
+#define WELLDUP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define WD_OK 0
+#define WD_ERR_ARG (-1)
+#define WD_ERR_INDEX (-2)
+#define WD_ERR_EMPTY_LEVEL (-3)
+#define WD_ERR_HIP (-4)
+#define WD_ERR_NOMEM (-5)
+#define WD_ERR_STATE (-6)
+#define WD_ERR_UNSUPPORTED (-7)
+#define WD_ERR_COMM (-8)
+
+/* Compare modes.  The reference counts a duplicate when dist <= edit_distance
+ * (count_well_duplicates.py:258) with dist = Levenshtein.distance, or Levenshtein.hamming
+ * under --hamming (:200).  WD_MODE_EQ is the `-e 0` corner (plain string equality under
+ * either metric); k is ignored there. */
+#define WD_MODE_EQ 0
+#define WD_MODE_HAMMING 1
+#define WD_MODE_LEVENSHTEIN 2
+
+#define WD_MAX_LEVELS 32
+#define WD_INVALID_TARGET 0xFFFFFFFFu
+
+typedef struct wd_ctx wd_ctx;
+
+/* ---- library / context ------------------------------------------------------------- */
+int wd_version(void);                    /* major*10000 + minor*100 + patch */
+const char *wd_strerror(int code);
+const char *wd_last_error(const wd_ctx *ctx);
+
+/* Creates a context on GPU `device_id` (-1 = current device).  Returns NULL on failure;
+ * wd_create_status() then holds the WD_ERR_* code of the failed attempt. */
+wd_ctx *wd_create(int device_id);
+int wd_create_status(void);
+void wd_destroy(wd_ctx *ctx);
+
+/* Run on a caller-owned HIP stream (hipStream_t, e.g. torch's current stream); NULL
+ * returns to the context's own stream. */
+int wd_set_stream(wd_ctx *ctx, void *hip_stream);
+int wd_synchronize(wd_ctx *ctx);
+
+/* Tunables, by name: "early_exit" (1), "targets_per_block" (8), "batch_first" (4),
+ * "batch_next" (8), "profile" (0).  Unknown names return WD_ERR_ARG. */
+int wd_set_option(wd_ctx *ctx, const char *name, int64_t value);
+int wd_get_option(wd_ctx *ctx, const char *name, int64_t *value);
+
+/* Device memory helpers, so a host program needs no other GPU runtime. */
+int wd_malloc(wd_ctx *ctx, size_t bytes, void **out_dev);
+int wd_free(wd_ctx *ctx, void *dev);
+int wd_memcpy_h2d(wd_ctx *ctx, void *dst_dev, const void *src_host, size_t bytes);
+int wd_memcpy_d2h(wd_ctx *ctx, void *dst_host, const void *src_dev, size_t bytes);
+int wd_memset(wd_ctx *ctx, void *dst_dev, int value, size_t bytes);
+
+/* ---- targets ----------------------------------------------------------------------- */
+/*
+ * Replaces: load_targets()/AllTargets/Target as consumed by the compare loop
+ * (target.py:6-40, :56-61, :118-128; count_well_duplicates.py:202-204, :228-230, :248).
+ *
+ * T targets in file order; for target t the wells of ring l (1-based, Target.get_indices(l))
+ * are nbr[lvl_off[t*(levels+1) + l-1] .. lvl_off[t*(levels+1) + l]).  Host pointers; the
+ * arrays are copied to the GPU and stay resident (one s.locs, hence one targets file, per
+ * flowcell).  levels <= WD_MAX_LEVELS.  Offsets must be non-decreasing and lie in
+ * [0, P] with P = lvl_off[T*(levels+1) - 1] (else WD_ERR_ARG).
+ */
+int wd_set_targets(wd_ctx *ctx, int T, int levels, const int32_t *centre,
+                   const int32_t *lvl_off, const int32_t *nbr);
+
+/* ---- the scan ---------------------------------------------------------------------- */
+/*
+ * Replaces, for n_tiles tiles at once: the per-tile body of main()
+ * (count_well_duplicates.py:212-265) - Tile.get_seqs() for every target well
+ * (bcl_direct_reader.py:158-220: byte 0 -> 'N', else "ACGT"[byte & 3], :352-361; filter
+ * flag = byte & 1, :246), the centre filter gate (:236-237), the per-level neighbour
+ * compare (:244-262) - plus the integer part of output_writer (:63-106).
+ *
+ *   planes  host array of n_tiles*L DEVICE pointers: planes[i*L + c] -> the N raw BCL
+ *           payload bytes (the file content after its 4-byte count header) of tile i,
+ *           c-th scanned cycle.  With --cycles a-b,c-d the ranges are concatenated, as
+ *           the reference joins the per-range strings (:238, :251).
+ *   filter  host array of n_tiles DEVICE pointers to the N raw .filter payload bytes
+ *           (after the 12-byte header).
+ *   N       clusters per tile.  Any centre or neighbour index outside [0, N) fails the
+ *           whole call with WD_ERR_INDEX before anything is launched (:186-192).
+ *   mode,k  WD_MODE_*; a neighbour is a duplicate when dist(centre, neighbour) <= k.
+ *   out_tile        n_tiles rows of 1 + 5*levels int64:
+ *                     [0]                     valid targets (centre passed the filter)
+ *                     [1 + 0*levels + l]      Wells: ring sizes summed over valid targets
+ *                     [1 + 1*levels + l]      Dups
+ *                     [1 + 2*levels + l]      Hit:   targets with >= 1 dup at level l
+ *                     [1 + 3*levels + l]      first: targets whose innermost hit level is l
+ *                     [1 + 4*levels + l]      last:  targets whose outermost hit level is l
+ *                   AccO = prefix sums of first, AccI = suffix sums of last (:80-89).
+ *   out_per_target  optional (NULL to skip): n_tiles*T*levels dup counts in target file
+ *                   order, WD_INVALID_TARGET in every level of a target whose centre failed
+ *                   the filter - enough to rebuild the reference's lane_dupl (:226, :265).
+ *
+ * wd_count_tiles: out_* are HOST pointers; synchronous; returns WD_ERR_EMPTY_LEVEL if a
+ * valid target has an empty ring (:249).
+ * wd_scan_async: out_* are DEVICE pointers; work is queued on the context's stream and the
+ * call returns at once; wd_scan_status() synchronises and returns the deferred status.
+ */
+int wd_count_tiles(wd_ctx *ctx, int n_tiles, int L, int mode, int k,
+                   const uint8_t *const *planes, const uint8_t *const *filter, int64_t N,
+                   int64_t *out_tile, uint32_t *out_per_target);
+
+int wd_scan_async(wd_ctx *ctx, int n_tiles, int L, int mode, int k,
+                  const uint8_t *const *planes, const uint8_t *const *filter, int64_t N,
+                  int64_t *out_tile_dev, uint32_t *out_per_target_dev);
+int wd_scan_status(wd_ctx *ctx);
+
+/*
+ * Duplicate log: the (centre, well, distance) records the reference prints to stderr for
+ * every duplicate (count_well_duplicates.py:258-262).  Enable with a capacity before a
+ * scan; afterwards fetch the records (unordered; sort by tile/target/slot on the host).
+ * total_out receives the number of duplicates seen, which may exceed the capacity.
+ */
+typedef struct wd_hit {
+    int32_t tile;      /* index into the call's tile list */
+    int32_t target;    /* index into the targets file */
+    int32_t slot;      /* position in nbr[] */
+    int32_t dist;      /* distance as the reference would print it (0 in WD_MODE_EQ) */
+} wd_hit;
+int wd_hitlog_enable(wd_ctx *ctx, int64_t capacity);   /* 0 disables */
+int wd_hitlog_fetch(wd_ctx *ctx, wd_hit *out_host, int64_t max_records, int64_t *total_out);
+
+/* Timing of the dominant kernel with HIP events on the stream it runs on ("profile"=1):
+ * total milliseconds and launches since the last reset. */
+int wd_profile_get(wd_ctx *ctx, double *total_ms, int64_t *launches);
+int wd_profile_reset(wd_ctx *ctx);
+
+/* ---- multi-GPU --------------------------------------------------------------------- */
+/*
+ * Tiles are independent (count_well_duplicates.py:207-226: one lane_dupl entry per tile,
+ * summed only in output_writer), so ranks take disjoint tile ranges and the only exchange
+ * is one in-place int64 sum of the zero-initialised [all tiles, 1+5*levels] block.
+ * RCCL is bound at run time (dlopen), so single-GPU use needs no RCCL at all.
+ */
+#define WD_UNIQUE_ID_BYTES 128
+int wd_comm_unique_id(void *out128);                      /* rank 0, then share the bytes */
+int wd_comm_init(wd_ctx *ctx, int rank, int world, const void *id128);
+int wd_allreduce_counts(wd_ctx *ctx, int64_t *buf_dev, size_t n);   /* in place, sum */
+int wd_comm_destroy(wd_ctx *ctx);
+
+/* ---- synthetic data (bench / tests) ------------------------------------------------ */
+/* Device-side twin of well_duplicates_amd/synth.py: byte-identical planes and filters. */
+typedef struct wd_synth_spec {
+    uint64_t seed;
+    int64_t n_clusters;
+    int64_t row;
+    uint32_t nocall_per_64k, pass_per_64k, plant_per_64k;
+    uint32_t filter_noise;
+    uint32_t tile_dead;
+} wd_synth_spec;
+int wd_synth_plane(wd_ctx *ctx, uint8_t *dst_dev, const wd_synth_spec *spec, int lane, int tile,
+                   int cycle);
+int wd_synth_filter(wd_ctx *ctx, uint8_t *dst_dev, const wd_synth_spec *spec, int lane, int tile);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* WELLDUP_H */

@@ -1,0 +1,127 @@
+"""Targets-file parser: the reference's own assertions (test/test_target.py:37-154) applied
+to the product parser (well_duplicates_amd.targets) and to the oracle's restatement."""
+import os
+
+import numpy as np
+import pytest
+
+from helpers import GOLD
+from oracle import oracle
+from well_duplicates_amd.targets import load_targets
+
+TEST_FILE = os.path.join(GOLD, "small.list")
+BAD_FILE_1 = os.path.join(GOLD, "bad1.list")
+BAD_FILE_2 = os.path.join(GOLD, "bad2.list")
+
+
+def ints(s):
+    return list(map(int, s.split(",")))
+
+
+def test_load_subset():
+    assert load_targets(TEST_FILE, levels=2).levels == 2
+
+
+def test_load_limit():
+    lim = load_targets(TEST_FILE, limit=2)
+    assert len(lim) == 2
+    assert sum(1 for _ in lim) == 2
+
+
+def test_get_all_indices():
+    lim = load_targets(TEST_FILE, levels=3, limit=2)
+    assert set(lim.get_all_indices(0)) == {1998850, 3178500}
+    assert set(lim.get_all_indices(1)) == set(ints(
+        "1997278,1997279,1998849,1998851,2000420,2000421,"
+        "3176929,3176930,3178499,3178501,3180071,3180072"))
+    assert set(lim.get_all_indices(None)) == set(ints(
+        "1998850,1997278,1997279,1998849,1998851,2000420,"
+        "2000421,1995707,1995708,1995709,1997277,1997280,"
+        "1998848,1998852,2000419,2000422,2001991,2001992,"
+        "2001993,3178500,3176929,3176930,3178499,3178501,"
+        "3180071,3180072,3175357,3175358,3175359,3176928,"
+        "3176931,3178498,3178502,3180070,3180073,3181641,"
+        "3181642,3181643"))
+
+
+def test_load_badfile():
+    with pytest.raises(ValueError):          # trailing blank line
+        load_targets(BAD_FILE_1)
+    with pytest.raises(AssertionError):      # last level line missing
+        load_targets(BAD_FILE_2)
+    with pytest.raises(ValueError):
+        oracle.py_load_targets(BAD_FILE_1)
+    with pytest.raises(AssertionError):
+        oracle.py_load_targets(BAD_FILE_2)
+
+
+def test_num_levels_and_targets():
+    t = load_targets(TEST_FILE)
+    assert t.levels == 4
+    assert t.get_target_by_centre(196654).get_levels() == 4
+    assert len(t) == 7
+    assert len(set(t.get_all_indices(0))) == 7
+
+
+def test_lookups():
+    t = load_targets(TEST_FILE)
+    res = t.get_from_index(196654)
+    targ = res[0][0]
+    assert res == [(targ, 0)]
+    assert targ.get_centre() == 196654
+    assert targ.get_indices(1) == ints("195083,195084,196653,196655,198225,198226")
+    gathered = set()
+    for lev in range(4):
+        gathered.update(targ.get_indices(lev))
+    assert gathered == set(targ.get_indices())
+
+
+def test_multiple_appearances():
+    t = load_targets(TEST_FILE)
+    assert len(set(t.get_all_indices())) == 213
+    res = t.get_from_index(1030466)
+    assert len(res) == 3
+    assert sorted(x[1] for x in res) == [2, 2, 3]
+
+
+def test_bad_add():
+    t = load_targets(TEST_FILE)
+    with pytest.raises(Exception):
+        t.add_target([(1, 2), (3, 4)])
+    with pytest.raises(AssertionError):
+        t.add_target([(111,), (112, 113, 114, 115)])
+    sub = load_targets(TEST_FILE, 2)
+    sub.add_target([(111,), (112, 113, 114, 115)])
+    with pytest.raises(Exception):
+        sub.add_target([(111,), (112, 113, 114, 115)])
+
+
+def test_iteration_order_is_file_order():
+    t = load_targets(TEST_FILE)
+    centres = [x.get_centre() for x in t]
+    first_ints = [int(l) for l in open(TEST_FILE).read().split("\n") if l and "," not in l]
+    assert centres == first_ints
+
+
+def test_csr_matches_lists_and_oracle_parser():
+    for levels in (1, 2, 3):
+        t = load_targets(TEST_FILE, levels=levels + 1)
+        centre, lvl_off, nbr = t.to_csr(levels)
+        ref = oracle.py_load_targets(TEST_FILE, levels=levels + 1)
+        assert len(ref) == len(t) == centre.shape[0]
+        for i, (targ, coords) in enumerate(zip(t, ref)):
+            assert centre[i] == coords[0][0] == targ.get_centre()
+            for lev in range(1, levels + 1):
+                got = nbr[lvl_off[i, lev - 1]:lvl_off[i, lev]].tolist()
+                assert got == coords[lev] == targ.get_indices(lev)
+        assert lvl_off[-1, -1] == nbr.shape[0]
+    with pytest.raises(ValueError):
+        load_targets(TEST_FILE, levels=2).to_csr(3)
+
+
+def test_limit_and_levels_like_cli():
+    # count_well_duplicates.py:202-204: levels = -l + 1, limit = -n
+    t = load_targets(TEST_FILE, levels=3, limit=5)
+    assert len(t) == 5 and t.levels == 3
+    ref = oracle.py_load_targets(TEST_FILE, levels=3, limit=5)
+    assert [c[0][0] for c in ref] == [x.get_centre() for x in t]

@@ -1,0 +1,117 @@
+"""ctypes binding of libwelldup.so (C ABI: include/welldup.h).
+
+The library is built in-tree by `build()` (hipcc --offload-arch=gfx950) and must exist:
+there is no CPU fallback for the scan path - `load()` raises if the shared object is
+missing or a symbol the header declares cannot be resolved.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(HERE)
+SRC = os.path.join(HERE, "csrc", "welldup.hip")
+INCLUDE = os.path.join(REPO, "include")
+LIB_PATH = os.path.join(HERE, "libwelldup.so")
+
+OK = 0
+ERR_ARG, ERR_INDEX, ERR_EMPTY_LEVEL, ERR_HIP, ERR_NOMEM, ERR_STATE, ERR_UNSUPPORTED, ERR_COMM = \
+    -1, -2, -3, -4, -5, -6, -7, -8
+MODE_EQ, MODE_HAMMING, MODE_LEVENSHTEIN = 0, 1, 2
+MAX_LEVELS = 32
+INVALID_TARGET = 0xFFFFFFFF
+UNIQUE_ID_BYTES = 128
+
+
+class Hit(ctypes.Structure):
+    _fields_ = [("tile", ctypes.c_int32), ("target", ctypes.c_int32),
+                ("slot", ctypes.c_int32), ("dist", ctypes.c_int32)]
+
+
+class SynthSpecC(ctypes.Structure):
+    _fields_ = [("seed", ctypes.c_uint64), ("n_clusters", ctypes.c_int64), ("row", ctypes.c_int64),
+                ("nocall_per_64k", ctypes.c_uint32), ("pass_per_64k", ctypes.c_uint32),
+                ("plant_per_64k", ctypes.c_uint32), ("filter_noise", ctypes.c_uint32),
+                ("tile_dead", ctypes.c_uint32)]
+
+
+_vp = ctypes.c_void_p
+_i = ctypes.c_int
+_i64 = ctypes.c_int64
+_sz = ctypes.c_size_t
+_pp = ctypes.POINTER(ctypes.c_void_p)
+
+# name -> (restype, argtypes); every symbol include/welldup.h declares
+PROTOTYPES = {
+    "wd_version": (_i, []),
+    "wd_strerror": (ctypes.c_char_p, [_i]),
+    "wd_last_error": (ctypes.c_char_p, [_vp]),
+    "wd_create": (_vp, [_i]),
+    "wd_create_status": (_i, []),
+    "wd_destroy": (None, [_vp]),
+    "wd_set_stream": (_i, [_vp, _vp]),
+    "wd_synchronize": (_i, [_vp]),
+    "wd_set_option": (_i, [_vp, ctypes.c_char_p, _i64]),
+    "wd_get_option": (_i, [_vp, ctypes.c_char_p, ctypes.POINTER(_i64)]),
+    "wd_malloc": (_i, [_vp, _sz, _pp]),
+    "wd_free": (_i, [_vp, _vp]),
+    "wd_memcpy_h2d": (_i, [_vp, _vp, _vp, _sz]),
+    "wd_memcpy_d2h": (_i, [_vp, _vp, _vp, _sz]),
+    "wd_memset": (_i, [_vp, _vp, _i, _sz]),
+    "wd_set_targets": (_i, [_vp, _i, _i, _vp, _vp, _vp]),
+    "wd_count_tiles": (_i, [_vp, _i, _i, _i, _i, _pp, _pp, _i64, _vp, _vp]),
+    "wd_scan_async": (_i, [_vp, _i, _i, _i, _i, _pp, _pp, _i64, _vp, _vp]),
+    "wd_scan_status": (_i, [_vp]),
+    "wd_hitlog_enable": (_i, [_vp, _i64]),
+    "wd_hitlog_fetch": (_i, [_vp, _vp, _i64, ctypes.POINTER(_i64)]),
+    "wd_profile_get": (_i, [_vp, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(_i64)]),
+    "wd_profile_reset": (_i, [_vp]),
+    "wd_comm_unique_id": (_i, [_vp]),
+    "wd_comm_init": (_i, [_vp, _i, _i, _vp]),
+    "wd_allreduce_counts": (_i, [_vp, _vp, _sz]),
+    "wd_comm_destroy": (_i, [_vp]),
+    "wd_synth_plane": (_i, [_vp, _vp, ctypes.POINTER(SynthSpecC), _i, _i, _i]),
+    "wd_synth_filter": (_i, [_vp, _vp, ctypes.POINTER(SynthSpecC), _i, _i]),
+}
+
+_lib = None
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    """Compile csrc/welldup.hip for gfx950 into the package directory."""
+    hdr = os.path.join(INCLUDE, "welldup.h")
+    if not force and os.path.exists(LIB_PATH):
+        newest = max(os.path.getmtime(SRC), os.path.getmtime(hdr))
+        if os.path.getmtime(LIB_PATH) >= newest:
+            return LIB_PATH
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    cmd = [hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-shared",
+           "-I" + INCLUDE, "-o", LIB_PATH, SRC]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return LIB_PATH
+
+
+def load():
+    """Load libwelldup.so and bind every prototype; raises if anything is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            "%s is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950). There is no CPU fallback for the scan path." % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH, mode=ctypes.RTLD_GLOBAL)
+    for name, (res, args) in PROTOTYPES.items():
+        fn = getattr(lib, name)          # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def strerror(code: int) -> str:
+    return load().wd_strerror(code).decode()

@@ -1,0 +1,1271 @@
+// welldup.hip - MI355X (gfx950 / CDNA4) well-duplicate scanner: kernels + C ABI.
+//
+// Hot path of EdinburghGenomics/well_duplicates' count_well_duplicates.py:228-265 (target ->
+// level -> neighbour compare) fused with the gather of Tile.get_seqs
+// (bcl_direct_reader.py:158-220, :352-361) and the integer part of output_writer
+// (count_well_duplicates.py:63-106).  Interface: include/welldup.h.
+//
+// Design (DESIGN.md has the full story)
+//   * One wave64 per target, one lane per neighbour slot ("entry").  Everything per-target
+//     (centre index, filter bit, ring offsets, the centre's base at each cycle) is
+//     wave-uniform; the per-level dup counts fall out of one __ballot + popcount per pass.
+//   * The gather is fused into the compare and is *lazy in the cycle direction*: a lane
+//     reads its well's byte for the first few cycles only; a neighbour that has already
+//     accumulated more than k mismatches (or whose banded edit-distance row is all > k) can
+//     never become a duplicate, so its remaining L - few bytes are never fetched.  On
+//     sequencing data almost every neighbour dies within 3-4 cycles, which removes ~90 % of
+//     the HBM sectors a full gather touches.  "early_exit"=0 gives the full gather.
+//   * HBM-bound byte/integer work: no MFMA, no LDS staging of sequences (each byte is used
+//     once).  LDS holds the block's tally histogram (LDS atomics), flushed with one global
+//     64-bit atomic per counter per block.
+//   * No CUDA shims, no dual paths: this file is gfx950 HIP only.
+#include <hip/hip_runtime.h>
+
+#include <dlfcn.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <algorithm>
+#include <string>
+#include <vector>
+
+#include "welldup.h"
+
+namespace {
+
+constexpr int kWave = 64;
+constexpr int kBlock = 256;
+constexpr int kWaves = kBlock / kWave;
+constexpr int kMaxLevels = WD_MAX_LEVELS;
+constexpr int kCounters = 1 + 5 * kMaxLevels;
+
+constexpr uint32_t kStatusEmptyLevel = 1u;
+
+// -------------------------------------------------------------------------------------
+// Synthetic data: device twin of well_duplicates_amd/synth.py (same constants, same bits)
+// -------------------------------------------------------------------------------------
+constexpr uint64_t K_SEED = 0x9E3779B97F4A7C15ull;
+constexpr uint64_t K_LANE = 0xD1B54A32D192ED03ull;
+constexpr uint64_t K_TILE = 0x8CB92BA72F3D8DD7ull;
+constexpr uint64_t K_CYCLE = 0xDB4F0B9175AE2165ull;
+constexpr uint64_t K_CLUSTER = 0xA24BAED4963EE407ull;
+constexpr uint64_t SALT_PLANT = 0x5851F42D4C957F2Dull;
+constexpr uint64_t SALT_FILTER = 0x2545F4914F6CDD1Dull;
+
+__host__ __device__ inline uint64_t mix64(uint64_t x)
+{
+    x ^= x >> 30;
+    x *= 0xBF58476D1CE4E5B9ull;
+    x ^= x >> 27;
+    x *= 0x94D049BB133111EBull;
+    x ^= x >> 31;
+    return x;
+}
+
+__device__ inline uint8_t synth_raw(uint64_t plane_key, uint64_t cluster, uint32_t nocall)
+{
+    uint64_t h = mix64(plane_key + cluster * K_CLUSTER);
+    if ((h & 0xFFFF) < nocall)
+        return 0;
+    uint32_t base = (uint32_t)(h >> 16) & 3u;
+    uint32_t qual = 2u + ((uint32_t)(h >> 18) & 0xFFFFu) % 39u;
+    return (uint8_t)((qual << 2) | base);
+}
+
+struct SynthPlaneArgs {
+    uint8_t *dst;
+    int64_t n, row;
+    uint64_t key_here, key_next, key_plant;
+    uint32_t nocall, plant;
+    int cycle;
+};
+
+__global__ __launch_bounds__(kBlock) void k_synth_plane(SynthPlaneArgs a)
+{
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < a.n; i += stride) {
+        uint64_t g = mix64(a.key_plant + (uint64_t)i * K_CLUSTER);
+        bool planted = (g & 0xFFFF) < a.plant;
+        uint32_t sel = ((uint32_t)(g >> 16) & 0xFFu) % 3u;
+        int64_t delta = sel == 0 ? 1 : (sel == 1 ? a.row : 2 * a.row);
+        int64_t src = i - delta;
+        planted = planted && src >= 0;
+        uint8_t b;
+        if (!planted) {
+            b = synth_raw(a.key_here, (uint64_t)i, a.nocall);
+        } else {
+            uint32_t variant = (uint32_t)(g >> 24) & 7u;
+            int sub1 = (int)(((uint32_t)(g >> 32) & 0xFFFFu) % 128u);
+            int sub2 = (int)(((uint32_t)(g >> 48) & 0xFFFFu) % 128u);
+            bool subst = ((variant == 5 || variant == 6) && sub1 == a.cycle) ||
+                         (variant == 6 && sub2 == a.cycle);
+            if (subst)
+                b = synth_raw(a.key_here, (uint64_t)i, a.nocall);
+            else if (variant == 7)
+                b = synth_raw(a.key_next, (uint64_t)src, a.nocall);
+            else
+                b = synth_raw(a.key_here, (uint64_t)src, a.nocall);
+        }
+        a.dst[i] = b;
+    }
+}
+
+struct SynthFilterArgs {
+    uint8_t *dst;
+    int64_t n;
+    uint64_t key;
+    uint32_t pass, noise, dead;
+};
+
+__global__ __launch_bounds__(kBlock) void k_synth_filter(SynthFilterArgs a)
+{
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < a.n; i += stride) {
+        uint64_t f = mix64(a.key + (uint64_t)i * K_CLUSTER);
+        uint8_t b = (!a.dead && (f & 0xFFFF) < a.pass) ? 1 : 0;
+        if (a.noise)
+            b |= (uint8_t)(((f >> 16) & 1) << 1);
+        a.dst[i] = b;
+    }
+}
+
+// -------------------------------------------------------------------------------------
+// Scan kernels
+// -------------------------------------------------------------------------------------
+struct ScanArgs {
+    const uint8_t *const *planes;   // device table: [n_tiles*L], or [n_tiles] bases if strided
+    const uint8_t *const *filter;   // device table [n_tiles]
+    int64_t stride;                 // bytes between consecutive cycle planes of a tile
+    const int32_t *centre;
+    const int32_t *lvl_off;
+    const int32_t *nbr;
+    unsigned long long *out_tile;   // [n_tiles][1 + 5*levels]
+    uint32_t *out_per_target;       // nullable [n_tiles][T][levels]
+    uint32_t *status;
+    wd_hit *hits;                   // nullable
+    unsigned long long *hit_count;
+    long long hit_cap;
+    int T, levels, L, k, tpb, early, check_empty;
+};
+
+// Symbol code of a BCL byte: 0 -> 4 ('N'), else byte & 3 (bcl_direct_reader.py:352-361).
+__device__ inline uint32_t code_of(uint32_t b)
+{
+    return (b & 3u) | (((b - 1u) >> 29) & 4u);
+}
+
+// Bits [lo, hi) of a 64-bit mask, lo/hi clamped to [0, 64].
+__device__ inline uint64_t range_mask(int lo, int hi)
+{
+    lo = lo < 0 ? 0 : (lo > 64 ? 64 : lo);
+    hi = hi < 0 ? 0 : (hi > 64 ? 64 : hi);
+    uint64_t mh = hi >= 64 ? ~0ull : ((1ull << hi) - 1ull);
+    uint64_t ml = lo >= 64 ? ~0ull : ((1ull << lo) - 1ull);
+    return mh & ~ml;
+}
+
+// ---- per-entry compare state: Hamming (also equality, k = 0) -------------------------
+struct HamState {
+    int mm;
+    __device__ void init(int) { mm = 0; }
+    // p = 1-based cycle just pushed; cc/wc = centre / well codes of that cycle
+    __device__ void push(int, uint64_t, uint32_t cc, uint32_t wc, int, int) { mm += (cc != wc); }
+    __device__ void finish(int, uint64_t, int, int) {}
+    __device__ bool alive(int k) const { return mm <= k; }
+    __device__ bool dup(int k) const { return mm <= k; }
+    __device__ int dist() const { return mm; }
+};
+
+// ---- per-entry compare state: Levenshtein <= k by a banded row DP ---------------------
+// Equal-length strings: a path of cost <= k never leaves diagonals |j - i| <= H = k / 2, so a
+// band of 2H+1 cells per row is exact for every pair with distance <= k and over-estimates
+// (never under-estimates) the rest.  Row i needs the well's codes w[i-H .. i+H], so it is
+// processed H cycles after cycle i arrives; values saturate at cap = k + 1.
+template <int H>
+struct LevState {
+    static constexpr int W = 2 * H + 1;
+    int r[W];
+    uint64_t wh;   // well codes, newest in bits [0,3)
+
+    __device__ void init(int cap)
+    {
+#pragma unroll
+        for (int d = 0; d < W; d++)
+            r[d] = d >= H ? min(d - H, cap) : cap;
+        wh = ~0ull;
+    }
+    // Row i (1-based) with centre code ci; wh's newest code is w[i + H].
+    __device__ void row(int i, uint32_t ci, int L, int cap)
+    {
+        int nw[W];
+#pragma unroll
+        for (int d = 0; d < W; d++) {
+            const int j = i + d - H;
+            const uint32_t wj = (uint32_t)(wh >> (3 * (2 * H - d))) & 7u;
+            int v = r[d] + (ci != wj ? 1 : 0);
+            if (d + 1 < W)
+                v = min(v, r[d + 1] + 1);
+            if (d > 0)
+                v = min(v, nw[d - 1] + 1);
+            v = (j == 0) ? i : v;
+            v = (j < 0 || j > L) ? cap : v;
+            nw[d] = min(v, cap);
+        }
+#pragma unroll
+        for (int d = 0; d < W; d++)
+            r[d] = nw[d];
+    }
+    // ch: centre codes, newest (cycle p) in bits [0,3)
+    __device__ void push(int p, uint64_t ch, uint32_t, uint32_t wc, int L, int cap)
+    {
+        wh = (wh << 3) | wc;
+        if (p > H)
+            row(p - H, (uint32_t)(ch >> (3 * H)) & 7u, L, cap);
+    }
+    // after cycle L: rows L-H+1 .. L still need processing; the missing codes never match
+    __device__ void finish(int L, uint64_t ch, int cap, int)
+    {
+#pragma unroll
+        for (int q = 1; q <= H; q++) {
+            wh = (wh << 3) | 7u;
+            ch = (ch << 3) | 6u;
+            const int i = L + q - H;
+            if (i >= 1)
+                row(i, (uint32_t)(ch >> (3 * H)) & 7u, L, cap);
+        }
+    }
+    __device__ bool alive(int k) const
+    {
+        bool a = false;
+#pragma unroll
+        for (int d = 0; d < W; d++)
+            a = a || (r[d] + (d > H ? d - H : H - d) <= k);
+        return a;
+    }
+    __device__ bool dup(int k) const { return r[H] <= k; }
+    __device__ int dist() const { return r[H]; }
+};
+
+// One wave = one target at a time; one lane = one neighbour slot (two slots per lane per
+// pass, 128 slots per pass).  B1 cycles are read unconditionally, then batches of B2 cycles
+// only by lanes that can still become a duplicate.
+template <class State, bool STRIDED, int B1, int B2>
+__global__ __launch_bounds__(kBlock) void k_scan(ScanArgs a)
+{
+    __shared__ uint32_t s_cnt[kCounters];
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int levels = a.levels;
+    const int L = a.L;
+    const int k = a.k;
+    const int cap = k + 1;
+    const int ncnt = 1 + 5 * levels;
+    const int chunks = (a.T + a.tpb - 1) / a.tpb;
+    const int tile = blockIdx.x / chunks;
+    const int chunk = blockIdx.x - tile * chunks;
+
+    for (int i = threadIdx.x; i < ncnt; i += kBlock)
+        s_cnt[i] = 0;
+    __syncthreads();
+
+    const uint8_t *filt = a.filter[tile];
+    const uint8_t *const *ptab = STRIDED ? nullptr : a.planes + (size_t)tile * L;
+    const uint8_t *base0 = STRIDED ? a.planes[tile] : nullptr;
+    const int64_t stride = a.stride;
+    auto plane_ptr = [&](int j) -> const uint8_t * {
+        return STRIDED ? base0 + (int64_t)j * stride : ptab[j];
+    };
+
+    const int t_end = min(a.T, (chunk + 1) * a.tpb);
+    for (int t = chunk * a.tpb + wave; t < t_end; t += kWaves) {
+        const int32_t *off = a.lvl_off + (size_t)t * (levels + 1);
+        const uint32_t c = (uint32_t)a.centre[t];
+        const int off0 = off[0];
+        const int K = off[levels] - off0;
+        // centre filter gate (count_well_duplicates.py:236-237)
+        const uint32_t fb = __builtin_amdgcn_readfirstlane((uint32_t)filt[c]);
+        uint32_t *opt = a.out_per_target
+                            ? a.out_per_target + ((size_t)tile * a.T + t) * levels
+                            : nullptr;
+        if (!(fb & 1u)) {
+            if (opt && lane < levels)
+                opt[lane] = WD_INVALID_TARGET;
+            continue;
+        }
+        int my_lo = 0, my_hi = 0;   // lane l < levels: ring l+1 is slots [my_lo, my_hi)
+        if (lane < levels) {
+            my_lo = off[lane] - off0;
+            my_hi = off[lane + 1] - off0;
+        }
+        if (a.check_empty) {        // count_well_duplicates.py:249
+            if (__ballot(lane < levels && my_hi <= my_lo)) {
+                if (lane == 0)
+                    atomicOr(a.status, kStatusEmptyLevel);
+                continue;
+            }
+        }
+        uint32_t my_d = 0;
+
+        for (int base = 0; base < K; base += 2 * kWave) {
+            const int e0 = base + lane, e1 = e0 + kWave;
+            const bool a0 = e0 < K, a1 = e1 < K;
+            // idle lanes shadow the centre well: their loads hit the centre's own line
+            const uint32_t i0 = a0 ? (uint32_t)a.nbr[off0 + e0] : c;
+            const uint32_t i1 = a1 ? (uint32_t)a.nbr[off0 + e1] : c;
+            State s0, s1;
+            s0.init(cap);
+            s1.init(cap);
+            uint64_t ch = ~0ull;          // centre codes, newest in bits [0,3)
+            bool l0 = a0, l1 = a1;        // still worth loading for
+            int j = 0;
+
+            // ---- first batch: unconditional ----
+            if (L > 0) {
+                uint32_t cb[B1], w0[B1], w1[B1];
+#pragma unroll
+                for (int q = 0; q < B1; q++) {
+                    const uint8_t *p = plane_ptr(min(j + q, L - 1));
+                    cb[q] = p[c];
+                    w0[q] = p[i0];
+                    w1[q] = p[i1];
+                }
+#pragma unroll
+                for (int q = 0; q < B1; q++) {
+                    if (j + q < L) {
+                        const uint32_t cc = code_of(cb[q]);
+                        ch = (ch << 3) | cc;
+                        s0.push(j + q + 1, ch, cc, code_of(w0[q]), L, cap);
+                        s1.push(j + q + 1, ch, cc, code_of(w1[q]), L, cap);
+                    }
+                }
+                j = min(L, B1);
+                if (a.early) {
+                    l0 = a0 && s0.alive(k);
+                    l1 = a1 && s1.alive(k);
+                }
+            }
+            // ---- later batches: only lanes that can still become a duplicate ----
+            while (j < L && __ballot(l0 || l1)) {
+                uint32_t cb[B2], w0[B2], w1[B2];
+                const uint8_t *pp[B2];
+#pragma unroll
+                for (int q = 0; q < B2; q++) {
+                    pp[q] = plane_ptr(min(j + q, L - 1));
+                    cb[q] = pp[q][c];
+                }
+                if (l0) {
+#pragma unroll
+                    for (int q = 0; q < B2; q++)
+                        w0[q] = pp[q][i0];
+                }
+                if (l1) {
+#pragma unroll
+                    for (int q = 0; q < B2; q++)
+                        w1[q] = pp[q][i1];
+                }
+#pragma unroll
+                for (int q = 0; q < B2; q++) {
+                    if (j + q < L) {
+                        const uint32_t cc = code_of(cb[q]);
+                        ch = (ch << 3) | cc;
+                        if (l0)
+                            s0.push(j + q + 1, ch, cc, code_of(w0[q]), L, cap);
+                        if (l1)
+                            s1.push(j + q + 1, ch, cc, code_of(w1[q]), L, cap);
+                    }
+                }
+                j = min(L, j + B2);
+                if (a.early) {
+                    l0 = l0 && s0.alive(k);
+                    l1 = l1 && s1.alive(k);
+                }
+            }
+            // lanes that made it through all L cycles
+            bool d0 = false, d1 = false;
+            if (j >= L) {
+                if (l0) {
+                    s0.finish(L, ch, cap, k);
+                    d0 = s0.dup(k);
+                }
+                if (l1) {
+                    s1.finish(L, ch, cap, k);
+                    d1 = s1.dup(k);
+                }
+            }
+            const uint64_t m0 = __ballot(d0), m1 = __ballot(d1);
+            if (m0 | m1) {
+                if (lane < levels) {
+                    my_d += __popcll(m0 & range_mask(my_lo - base, my_hi - base));
+                    my_d += __popcll(m1 & range_mask(my_lo - base - kWave, my_hi - base - kWave));
+                }
+                if (a.hits) {
+                    if (d0) {
+                        unsigned long long h = atomicAdd(a.hit_count, 1ull);
+                        if ((long long)h < a.hit_cap)
+                            a.hits[h] = wd_hit{tile, t, off0 + e0, s0.dist()};
+                    }
+                    if (d1) {
+                        unsigned long long h = atomicAdd(a.hit_count, 1ull);
+                        if ((long long)h < a.hit_cap)
+                            a.hits[h] = wd_hit{tile, t, off0 + e1, s1.dist()};
+                    }
+                }
+            }
+        }
+
+        // ---- tally (count_well_duplicates.py:80-95 as histograms; include/welldup.h) ----
+        const uint64_t hm = __ballot(lane < levels && my_d > 0);
+        if (lane < levels) {
+            atomicAdd(&s_cnt[1 + lane], (uint32_t)(my_hi - my_lo));
+            if (my_d) {
+                atomicAdd(&s_cnt[1 + levels + lane], my_d);
+                atomicAdd(&s_cnt[1 + 2 * levels + lane], 1u);
+            }
+            if (opt)
+                opt[lane] = my_d;
+        }
+        if (lane == 0) {
+            atomicAdd(&s_cnt[0], 1u);
+            if (hm) {
+                atomicAdd(&s_cnt[1 + 3 * levels + (__ffsll((long long)hm) - 1)], 1u);
+                atomicAdd(&s_cnt[1 + 4 * levels + (63 - __clzll((long long)hm))], 1u);
+            }
+        }
+    }
+
+    __syncthreads();
+    for (int i = threadIdx.x; i < ncnt; i += kBlock) {
+        const uint32_t v = s_cnt[i];
+        if (v)
+            atomicAdd(&a.out_tile[(size_t)tile * ncnt + i], (unsigned long long)v);
+    }
+}
+
+// -------------------------------------------------------------------------------------
+// RCCL, bound at run time
+// -------------------------------------------------------------------------------------
+struct Id128 { char b[WD_UNIQUE_ID_BYTES]; };   // ncclUniqueId, passed by value
+struct Rccl {
+    void *handle = nullptr;
+    int (*GetUniqueId)(void *) = nullptr;
+    int (*CommInitRank)(void **, int, Id128, int) = nullptr;
+    int (*AllReduce)(const void *, void *, size_t, int, int, void *, hipStream_t) = nullptr;
+    int (*CommDestroy)(void *) = nullptr;
+    const char *(*GetErrorString)(int) = nullptr;
+};
+Rccl g_rccl;
+
+bool rccl_load(std::string &err)
+{
+    if (g_rccl.handle)
+        return true;
+    const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    void *h = nullptr;
+    for (const char *n : names) {
+        h = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+        if (h)
+            break;
+    }
+    if (!h) {
+        err = std::string("cannot load librccl: ") + dlerror();
+        return false;
+    }
+    auto sym = [&](const char *s) { return dlsym(h, s); };
+    g_rccl.GetUniqueId = (decltype(g_rccl.GetUniqueId))sym("ncclGetUniqueId");
+    g_rccl.CommInitRank = (decltype(g_rccl.CommInitRank))sym("ncclCommInitRank");
+    g_rccl.AllReduce = (decltype(g_rccl.AllReduce))sym("ncclAllReduce");
+    g_rccl.CommDestroy = (decltype(g_rccl.CommDestroy))sym("ncclCommDestroy");
+    g_rccl.GetErrorString = (decltype(g_rccl.GetErrorString))sym("ncclGetErrorString");
+    if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.AllReduce || !g_rccl.CommDestroy) {
+        err = "librccl lacks the nccl* entry points";
+        return false;
+    }
+    g_rccl.handle = h;
+    return true;
+}
+
+int g_create_status = WD_OK;
+
+}  // namespace
+
+// -------------------------------------------------------------------------------------
+// Context
+// -------------------------------------------------------------------------------------
+struct wd_ctx {
+    int device = 0;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+    std::string err;
+
+    // options
+    int early_exit = 1;
+    int tpb = 8;
+    int batch_first = 4;
+    int batch_next = 8;
+    int profile = 0;
+
+    // targets (device)
+    int T = 0, levels = 0;
+    int64_t P = 0;
+    int32_t *d_centre = nullptr, *d_lvl_off = nullptr, *d_nbr = nullptr;
+    int64_t idx_min = 0, idx_max = -1;
+    bool has_targets = false;
+    bool has_empty_level = false;
+
+    // per-call tables
+    std::vector<const uint8_t *> h_tbl;      // last uploaded pointer table (planes then filter)
+    const uint8_t **d_tbl = nullptr;
+    size_t d_tbl_cap = 0;
+    uint32_t *d_status = nullptr;
+    uint32_t *h_status = nullptr;            // pinned
+
+    // sync-call scratch
+    unsigned long long *d_out_tile = nullptr;
+    size_t d_out_tile_cap = 0;
+    uint32_t *d_out_pt = nullptr;
+    size_t d_out_pt_cap = 0;
+
+    // hit log
+    wd_hit *d_hits = nullptr;
+    unsigned long long *d_hit_count = nullptr;
+    int64_t hit_cap = 0;
+
+    // profile
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> free_events;
+    double prof_ms = 0.0;
+    int64_t prof_launches = 0;
+
+    // comm
+    void *comm = nullptr;
+};
+
+namespace {
+
+int fail(wd_ctx *ctx, int code, const std::string &msg)
+{
+    if (ctx)
+        ctx->err = msg;
+    return code;
+}
+
+#define WD_HIP(ctx, call)                                                                 \
+    do {                                                                                  \
+        hipError_t e_ = (call);                                                           \
+        if (e_ != hipSuccess)                                                             \
+            return fail((ctx), e_ == hipErrorOutOfMemory ? WD_ERR_NOMEM : WD_ERR_HIP,     \
+                        std::string(#call) + ": " + hipGetErrorString(e_));               \
+    } while (0)
+
+int bind_device(wd_ctx *ctx)
+{
+    WD_HIP(ctx, hipSetDevice(ctx->device));
+    return WD_OK;
+}
+
+template <class T>
+int grow(wd_ctx *ctx, T *&ptr, size_t &cap, size_t need)
+{
+    if (need <= cap)
+        return WD_OK;
+    if (ptr) {
+        WD_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        WD_HIP(ctx, hipFree(ptr));
+        ptr = nullptr;
+        cap = 0;
+    }
+    WD_HIP(ctx, hipMalloc((void **)&ptr, need * sizeof(T)));
+    cap = need;
+    return WD_OK;
+}
+
+void drain_events(wd_ctx *ctx)
+{
+    for (auto &ev : ctx->events) {
+        float ms = 0.f;
+        if (hipEventSynchronize(ev.second) == hipSuccess &&
+            hipEventElapsedTime(&ms, ev.first, ev.second) == hipSuccess) {
+            ctx->prof_ms += ms;
+            ctx->prof_launches += 1;
+        }
+        ctx->free_events.push_back(ev);
+    }
+    ctx->events.clear();
+}
+
+// Batch shapes (cycles read unconditionally, then per conditional batch).  The Hamming family
+// is instantiated for a few shapes so they can be tuned; the banded edit-distance family
+// needs ~2x the cycles before a random neighbour dies, so it uses one deeper shape.
+constexpr int kHamShapes[][2] = {{2, 4}, {3, 4}, {4, 4}, {4, 8}, {8, 8}};
+constexpr int kLevB1 = 8, kLevB2 = 8;
+
+template <bool STRIDED>
+void launch_ham(wd_ctx *ctx, const ScanArgs &a, dim3 grid)
+{
+    const int b1 = ctx->batch_first, b2 = ctx->batch_next;
+#define WD_CASE(B1, B2)                                                                   \
+    if (b1 == B1 && b2 == B2) {                                                           \
+        hipLaunchKernelGGL((k_scan<HamState, STRIDED, B1, B2>), grid, dim3(kBlock), 0,    \
+                           ctx->stream, a);                                               \
+        return;                                                                           \
+    }
+    WD_CASE(2, 4)
+    WD_CASE(3, 4)
+    WD_CASE(4, 4)
+    WD_CASE(4, 8)
+    WD_CASE(8, 8)
+#undef WD_CASE
+}
+
+template <int H>
+void launch_lev(wd_ctx *ctx, const ScanArgs &a, dim3 grid, bool strided)
+{
+    if (strided)
+        hipLaunchKernelGGL((k_scan<LevState<H>, true, kLevB1, kLevB2>), grid, dim3(kBlock), 0,
+                           ctx->stream, a);
+    else
+        hipLaunchKernelGGL((k_scan<LevState<H>, false, kLevB1, kLevB2>), grid, dim3(kBlock), 0,
+                           ctx->stream, a);
+}
+
+bool valid_batches(int b1, int b2)
+{
+    for (auto &p : kHamShapes)
+        if (p[0] == b1 && p[1] == b2)
+            return true;
+    return false;
+}
+
+}  // namespace
+
+// -------------------------------------------------------------------------------------
+// C ABI
+// -------------------------------------------------------------------------------------
+extern "C" {
+
+int wd_version(void) { return 100; }
+
+const char *wd_strerror(int code)
+{
+    switch (code) {
+    case WD_OK: return "ok";
+    case WD_ERR_ARG: return "invalid argument";
+    case WD_ERR_INDEX: return "cluster index out of range for this tile";
+    case WD_ERR_EMPTY_LEVEL: return "a valid target has an empty level";
+    case WD_ERR_HIP: return "HIP runtime error";
+    case WD_ERR_NOMEM: return "out of device memory";
+    case WD_ERR_STATE: return "call out of order (targets not set?)";
+    case WD_ERR_UNSUPPORTED: return "unsupported parameter combination";
+    case WD_ERR_COMM: return "RCCL error";
+    default: return "unknown error";
+    }
+}
+
+const char *wd_last_error(const wd_ctx *ctx) { return ctx ? ctx->err.c_str() : ""; }
+
+int wd_create_status(void) { return g_create_status; }
+
+wd_ctx *wd_create(int device_id)
+{
+    g_create_status = WD_OK;
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0) {
+        g_create_status = WD_ERR_HIP;
+        return nullptr;
+    }
+    if (device_id < 0) {
+        if (hipGetDevice(&device_id) != hipSuccess)
+            device_id = 0;
+    }
+    if (device_id >= ndev) {
+        g_create_status = WD_ERR_ARG;
+        return nullptr;
+    }
+    wd_ctx *ctx = new wd_ctx();
+    ctx->device = device_id;
+    if (hipSetDevice(device_id) != hipSuccess ||
+        hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking) != hipSuccess ||
+        hipMalloc((void **)&ctx->d_status, sizeof(uint32_t)) != hipSuccess ||
+        hipHostMalloc((void **)&ctx->h_status, sizeof(uint32_t), hipHostMallocDefault) != hipSuccess ||
+        hipMalloc((void **)&ctx->d_hit_count, sizeof(unsigned long long)) != hipSuccess) {
+        g_create_status = WD_ERR_HIP;
+        delete ctx;
+        return nullptr;
+    }
+    ctx->stream = ctx->own_stream;
+    (void)hipMemsetAsync(ctx->d_status, 0, sizeof(uint32_t), ctx->stream);
+    (void)hipMemsetAsync(ctx->d_hit_count, 0, sizeof(unsigned long long), ctx->stream);
+    (void)hipStreamSynchronize(ctx->stream);
+    return ctx;
+}
+
+void wd_destroy(wd_ctx *ctx)
+{
+    if (!ctx)
+        return;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    drain_events(ctx);
+    for (auto &ev : ctx->free_events) {
+        (void)hipEventDestroy(ev.first);
+        (void)hipEventDestroy(ev.second);
+    }
+    if (ctx->comm && g_rccl.CommDestroy)
+        g_rccl.CommDestroy(ctx->comm);
+    (void)hipFree(ctx->d_centre);
+    (void)hipFree(ctx->d_lvl_off);
+    (void)hipFree(ctx->d_nbr);
+    (void)hipFree(ctx->d_tbl);
+    (void)hipFree(ctx->d_status);
+    (void)hipHostFree(ctx->h_status);
+    (void)hipFree(ctx->d_out_tile);
+    (void)hipFree(ctx->d_out_pt);
+    (void)hipFree(ctx->d_hits);
+    (void)hipFree(ctx->d_hit_count);
+    if (ctx->own_stream)
+        (void)hipStreamDestroy(ctx->own_stream);
+    delete ctx;
+}
+
+int wd_set_stream(wd_ctx *ctx, void *hip_stream)
+{
+    if (!ctx)
+        return WD_ERR_ARG;
+    if (bind_device(ctx))
+        return WD_ERR_HIP;
+    WD_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
+    return WD_OK;
+}
+
+int wd_synchronize(wd_ctx *ctx)
+{
+    if (!ctx)
+        return WD_ERR_ARG;
+    if (bind_device(ctx))
+        return WD_ERR_HIP;
+    WD_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return WD_OK;
+}
+
+int wd_set_option(wd_ctx *ctx, const char *name, int64_t value)
+{
+    if (!ctx || !name)
+        return WD_ERR_ARG;
+    std::string n(name);
+    if (n == "early_exit") {
+        ctx->early_exit = value ? 1 : 0;
+    } else if (n == "targets_per_block") {
+        if (value < 1 || value > 4096)
+            return fail(ctx, WD_ERR_ARG, "targets_per_block out of range");
+        ctx->tpb = (int)value;
+    } else if (n == "batch_first") {
+        ctx->batch_first = (int)value;
+    } else if (n == "batch_next") {
+        ctx->batch_next = (int)value;
+    } else if (n == "profile") {
+        ctx->profile = value ? 1 : 0;
+    } else {
+        return fail(ctx, WD_ERR_ARG, "unknown option " + n);
+    }
+    return WD_OK;
+}
+
+int wd_get_option(wd_ctx *ctx, const char *name, int64_t *value)
+{
+    if (!ctx || !name || !value)
+        return WD_ERR_ARG;
+    std::string n(name);
+    if (n == "early_exit") *value = ctx->early_exit;
+    else if (n == "targets_per_block") *value = ctx->tpb;
+    else if (n == "batch_first") *value = ctx->batch_first;
+    else if (n == "batch_next") *value = ctx->batch_next;
+    else if (n == "profile") *value = ctx->profile;
+    else return fail(ctx, WD_ERR_ARG, "unknown option " + n);
+    return WD_OK;
+}
+
+int wd_malloc(wd_ctx *ctx, size_t bytes, void **out_dev)
+{
+    if (!ctx || !out_dev)
+        return WD_ERR_ARG;
+    if (bind_device(ctx))
+        return WD_ERR_HIP;
+    *out_dev = nullptr;
+    WD_HIP(ctx, hipMalloc(out_dev, bytes ? bytes : 1));
+    return WD_OK;
+}
+
+int wd_free(wd_ctx *ctx, void *dev)
+{
+    if (!ctx)
+        return WD_ERR_ARG;
+    if (bind_device(ctx))
+        return WD_ERR_HIP;
+    WD_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    WD_HIP(ctx, hipFree(dev));
+    return WD_OK;
+}
+
+int wd_memcpy_h2d(wd_ctx *ctx, void *dst_dev, const void *src_host, size_t bytes)
+{
+    if (!ctx)
+        return WD_ERR_ARG;
+    if (bind_device(ctx))
+        return WD_ERR_HIP;
+    WD_HIP(ctx, hipMemcpyAsync(dst_dev, src_host, bytes, hipMemcpyHostToDevice, ctx->stream));
+    WD_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return WD_OK;
+}
+
+int wd_memcpy_d2h(wd_ctx *ctx, void *dst_host, const void *src_dev, size_t bytes)
+{
+    if (!ctx)
+        return WD_ERR_ARG;
+    if (bind_device(ctx))
+        return WD_ERR_HIP;
+    WD_HIP(ctx, hipMemcpyAsync(dst_host, src_dev, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    WD_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return WD_OK;
+}
+
+int wd_memset(wd_ctx *ctx, void *dst_dev, int value, size_t bytes)
+{
+    if (!ctx)
+        return WD_ERR_ARG;
+    if (bind_device(ctx))
+        return WD_ERR_HIP;
+    WD_HIP(ctx, hipMemsetAsync(dst_dev, value, bytes, ctx->stream));
+    return WD_OK;
+}
+
+int wd_set_targets(wd_ctx *ctx, int T, int levels, const int32_t *centre, const int32_t *lvl_off,
+                   const int32_t *nbr)
+{
+    if (!ctx || T < 0 || levels < 0 || levels > kMaxLevels)
+        return fail(ctx, WD_ERR_ARG, "bad T or levels");
+    if (T > 0 && (!centre || !lvl_off))
+        return fail(ctx, WD_ERR_ARG, "null targets array");
+    if (bind_device(ctx))
+        return WD_ERR_HIP;
+    int64_t P = 0;
+    bool empty = false;
+    int64_t lo = INT64_MAX, hi = INT64_MIN;
+    const size_t row = (size_t)levels + 1;
+    for (int t = 0; t < T; t++) {
+        const int32_t *o = lvl_off + (size_t)t * row;
+        for (int l = 0; l < levels; l++) {
+            if (o[l + 1] < o[l] || o[l] < 0)
+                return fail(ctx, WD_ERR_ARG, "lvl_off must be non-decreasing and >= 0");
+            if (o[l + 1] == o[l])
+                empty = true;
+        }
+        if (o[0] < 0)
+            return fail(ctx, WD_ERR_ARG, "lvl_off must be >= 0");
+        P = std::max<int64_t>(P, o[levels]);
+        lo = std::min<int64_t>(lo, centre[t]);
+        hi = std::max<int64_t>(hi, centre[t]);
+    }
+    if (P > 0 && !nbr)
+        return fail(ctx, WD_ERR_ARG, "null nbr array");
+    // only slots some target refers to are range-checked (get_all_indices, target.py:93-95)
+    for (int t = 0; t < T; t++) {
+        const int32_t *o = lvl_off + (size_t)t * row;
+        for (int64_t p = o[0]; p < o[levels]; p++) {
+            lo = std::min<int64_t>(lo, nbr[p]);
+            hi = std::max<int64_t>(hi, nbr[p]);
+        }
+    }
+    WD_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    (void)hipFree(ctx->d_centre);
+    (void)hipFree(ctx->d_lvl_off);
+    (void)hipFree(ctx->d_nbr);
+    ctx->d_centre = ctx->d_lvl_off = ctx->d_nbr = nullptr;
+    ctx->has_targets = false;
+    WD_HIP(ctx, hipMalloc((void **)&ctx->d_centre, std::max<size_t>(1, T) * sizeof(int32_t)));
+    WD_HIP(ctx, hipMalloc((void **)&ctx->d_lvl_off, std::max<size_t>(1, T * row) * sizeof(int32_t)));
+    WD_HIP(ctx, hipMalloc((void **)&ctx->d_nbr, std::max<int64_t>(1, P) * sizeof(int32_t)));
+    if (T > 0) {
+        WD_HIP(ctx, hipMemcpy(ctx->d_centre, centre, (size_t)T * sizeof(int32_t), hipMemcpyHostToDevice));
+        WD_HIP(ctx, hipMemcpy(ctx->d_lvl_off, lvl_off, (size_t)T * row * sizeof(int32_t), hipMemcpyHostToDevice));
+    }
+    if (P > 0)
+        WD_HIP(ctx, hipMemcpy(ctx->d_nbr, nbr, (size_t)P * sizeof(int32_t), hipMemcpyHostToDevice));
+    ctx->T = T;
+    ctx->levels = levels;
+    ctx->P = P;
+    ctx->idx_min = T ? lo : 0;
+    ctx->idx_max = T ? hi : -1;
+    ctx->has_empty_level = empty;
+    ctx->has_targets = true;
+    return WD_OK;
+}
+
+int wd_scan_async(wd_ctx *ctx, int n_tiles, int L, int mode, int k, const uint8_t *const *planes,
+                  const uint8_t *const *filter, int64_t N, int64_t *out_tile_dev,
+                  uint32_t *out_per_target_dev)
+{
+    if (!ctx)
+        return WD_ERR_ARG;
+    if (!ctx->has_targets)
+        return fail(ctx, WD_ERR_STATE, "wd_set_targets has not been called");
+    if (n_tiles < 0 || L < 0 || N < 0 || !out_tile_dev)
+        return fail(ctx, WD_ERR_ARG, "bad n_tiles, L, N or out_tile");
+    if (mode != WD_MODE_EQ && mode != WD_MODE_HAMMING && mode != WD_MODE_LEVENSHTEIN)
+        return fail(ctx, WD_ERR_ARG, "bad mode");
+    if (n_tiles > 0 && (!filter || (L > 0 && !planes)))
+        return fail(ctx, WD_ERR_ARG, "null plane/filter table");
+    if (!valid_batches(ctx->batch_first, ctx->batch_next))
+        return fail(ctx, WD_ERR_ARG, "unsupported batch_first/batch_next pair");
+    if (bind_device(ctx))
+        return WD_ERR_HIP;
+    // Tile.get_seqs: every requested index must lie inside the tile (bcl_direct_reader.py:186-192)
+    if (ctx->T > 0 && n_tiles > 0 && (ctx->idx_min < 0 || ctx->idx_max >= N))
+        return fail(ctx, WD_ERR_INDEX, "a target index lies outside [0, N)");
+
+    const int levels = ctx->levels;
+    const size_t ncnt = 1 + 5 * (size_t)levels;
+    WD_HIP(ctx, hipMemsetAsync(out_tile_dev, 0, (size_t)n_tiles * ncnt * sizeof(int64_t), ctx->stream));
+    if (n_tiles == 0 || ctx->T == 0)
+        return WD_OK;
+
+    // normalise the compare: equality and Levenshtein <= 1 are Hamming problems
+    int kk = k;
+    bool lev = false;
+    if (mode == WD_MODE_EQ) {
+        kk = 0;
+    } else if (mode == WD_MODE_LEVENSHTEIN) {
+        if (k >= L) {
+            kk = L;                 // every equal-length pair is within L substitutions
+        } else if (k >= 2) {
+            lev = true;
+        }                            // k <= 1: equal lengths, so one edit is one substitution
+    }
+    if (kk > L)
+        kk = L;
+    if (kk < -1)
+        kk = -1;
+    if (lev && kk / 2 > 8)
+        return fail(ctx, WD_ERR_UNSUPPORTED, "Levenshtein threshold 18 <= k < L is not implemented yet");
+
+    // pointer tables: uniform plane stride -> per-tile base only
+    bool strided = L > 0;
+    int64_t stride = 0;
+    if (L > 1)
+        stride = (int64_t)(planes[1] - planes[0]);
+    for (int i = 0; i < n_tiles && strided; i++)
+        for (int c = 1; c < L; c++)
+            if ((int64_t)(planes[(size_t)i * L + c] - planes[(size_t)i * L]) != stride * c) {
+                strided = false;
+                break;
+            }
+    const size_t n_plane_ptrs = strided ? (size_t)n_tiles : (size_t)n_tiles * L;
+    std::vector<const uint8_t *> tbl(n_plane_ptrs + n_tiles);
+    for (int i = 0; i < n_tiles; i++) {
+        if (strided)
+            tbl[i] = planes[(size_t)i * L];
+        else
+            for (int c = 0; c < L; c++)
+                tbl[(size_t)i * L + c] = planes[(size_t)i * L + c];
+        tbl[n_plane_ptrs + i] = filter[i];
+    }
+    if (tbl != ctx->h_tbl) {
+        int rc = grow(ctx, ctx->d_tbl, ctx->d_tbl_cap, tbl.size());
+        if (rc)
+            return rc;
+        // the previous table may still be read by queued kernels
+        WD_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        WD_HIP(ctx, hipMemcpy(ctx->d_tbl, tbl.data(), tbl.size() * sizeof(void *), hipMemcpyHostToDevice));
+        ctx->h_tbl.swap(tbl);
+    }
+
+    ScanArgs a;
+    a.planes = ctx->d_tbl;
+    a.filter = ctx->d_tbl + n_plane_ptrs;
+    a.stride = stride;
+    a.centre = ctx->d_centre;
+    a.lvl_off = ctx->d_lvl_off;
+    a.nbr = ctx->d_nbr;
+    a.out_tile = (unsigned long long *)out_tile_dev;
+    a.out_per_target = out_per_target_dev;
+    a.status = ctx->d_status;
+    a.hits = ctx->hit_cap > 0 ? ctx->d_hits : nullptr;
+    a.hit_count = ctx->d_hit_count;
+    a.hit_cap = ctx->hit_cap;
+    a.T = ctx->T;
+    a.levels = levels;
+    a.L = L;
+    a.k = kk;
+    a.tpb = ctx->tpb;
+    a.early = ctx->early_exit;
+    a.check_empty = ctx->has_empty_level ? 1 : 0;
+    if (ctx->hit_cap > 0)
+        WD_HIP(ctx, hipMemsetAsync(ctx->d_hit_count, 0, sizeof(unsigned long long), ctx->stream));
+
+    const int chunks = (ctx->T + ctx->tpb - 1) / ctx->tpb;
+    const long long nblocks = (long long)chunks * n_tiles;
+    if (nblocks > 0x7FFFFFFFll)
+        return fail(ctx, WD_ERR_UNSUPPORTED, "grid too large; raise targets_per_block");
+    dim3 grid((unsigned)nblocks);
+
+    std::pair<hipEvent_t, hipEvent_t> ev{nullptr, nullptr};
+    if (ctx->profile) {
+        if (!ctx->free_events.empty()) {
+            ev = ctx->free_events.back();
+            ctx->free_events.pop_back();
+        } else {
+            WD_HIP(ctx, hipEventCreate(&ev.first));
+            WD_HIP(ctx, hipEventCreate(&ev.second));
+        }
+        WD_HIP(ctx, hipEventRecord(ev.first, ctx->stream));
+    }
+    if (!lev) {
+        if (strided)
+            launch_ham<true>(ctx, a, grid);
+        else
+            launch_ham<false>(ctx, a, grid);
+    } else {
+        const int h = kk / 2;
+        if (h <= 1) launch_lev<1>(ctx, a, grid, strided);
+        else if (h <= 2) launch_lev<2>(ctx, a, grid, strided);
+        else if (h <= 3) launch_lev<3>(ctx, a, grid, strided);
+        else if (h <= 4) launch_lev<4>(ctx, a, grid, strided);
+        else if (h <= 6) launch_lev<6>(ctx, a, grid, strided);
+        else launch_lev<8>(ctx, a, grid, strided);
+    }
+    WD_HIP(ctx, hipGetLastError());
+    if (ctx->profile) {
+        WD_HIP(ctx, hipEventRecord(ev.second, ctx->stream));
+        ctx->events.push_back(ev);
+    }
+    return WD_OK;
+}
+
+int wd_scan_status(wd_ctx *ctx)
+{
+    if (!ctx)
+        return WD_ERR_ARG;
+    if (bind_device(ctx))
+        return WD_ERR_HIP;
+    WD_HIP(ctx, hipMemcpyAsync(ctx->h_status, ctx->d_status, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+    WD_HIP(ctx, hipMemsetAsync(ctx->d_status, 0, sizeof(uint32_t), ctx->stream));
+    WD_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (*ctx->h_status & kStatusEmptyLevel)
+        return fail(ctx, WD_ERR_EMPTY_LEVEL, "a target with a valid centre has an empty level");
+    return WD_OK;
+}
+
+int wd_count_tiles(wd_ctx *ctx, int n_tiles, int L, int mode, int k, const uint8_t *const *planes,
+                   const uint8_t *const *filter, int64_t N, int64_t *out_tile,
+                   uint32_t *out_per_target)
+{
+    if (!ctx || !out_tile)
+        return WD_ERR_ARG;
+    if (!ctx->has_targets)
+        return fail(ctx, WD_ERR_STATE, "wd_set_targets has not been called");
+    if (n_tiles < 0)
+        return fail(ctx, WD_ERR_ARG, "bad n_tiles");
+    if (bind_device(ctx))
+        return WD_ERR_HIP;
+    const size_t ncnt = 1 + 5 * (size_t)ctx->levels;
+    const size_t n_out = std::max<size_t>(1, (size_t)n_tiles * ncnt);
+    const size_t n_pt = std::max<size_t>(1, (size_t)n_tiles * ctx->T * ctx->levels);
+    int rc = grow(ctx, ctx->d_out_tile, ctx->d_out_tile_cap, n_out);
+    if (rc)
+        return rc;
+    if (out_per_target) {
+        rc = grow(ctx, ctx->d_out_pt, ctx->d_out_pt_cap, n_pt);
+        if (rc)
+            return rc;
+    }
+    rc = wd_scan_async(ctx, n_tiles, L, mode, k, planes, filter, N, (int64_t *)ctx->d_out_tile,
+                       out_per_target ? ctx->d_out_pt : nullptr);
+    if (rc)
+        return rc;
+    rc = wd_scan_status(ctx);
+    if (rc)
+        return rc;
+    if (n_tiles > 0) {
+        WD_HIP(ctx, hipMemcpy(out_tile, ctx->d_out_tile, (size_t)n_tiles * ncnt * sizeof(int64_t), hipMemcpyDeviceToHost));
+        if (out_per_target && ctx->T > 0 && ctx->levels > 0)
+            WD_HIP(ctx, hipMemcpy(out_per_target, ctx->d_out_pt,
+                                  (size_t)n_tiles * ctx->T * ctx->levels * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    }
+    return WD_OK;
+}
+
+int wd_hitlog_enable(wd_ctx *ctx, int64_t capacity)
+{
+    if (!ctx || capacity < 0)
+        return WD_ERR_ARG;
+    if (bind_device(ctx))
+        return WD_ERR_HIP;
+    WD_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    (void)hipFree(ctx->d_hits);
+    ctx->d_hits = nullptr;
+    ctx->hit_cap = 0;
+    if (capacity > 0) {
+        WD_HIP(ctx, hipMalloc((void **)&ctx->d_hits, (size_t)capacity * sizeof(wd_hit)));
+        ctx->hit_cap = capacity;
+    }
+    WD_HIP(ctx, hipMemsetAsync(ctx->d_hit_count, 0, sizeof(unsigned long long), ctx->stream));
+    return WD_OK;
+}
+
+int wd_hitlog_fetch(wd_ctx *ctx, wd_hit *out_host, int64_t max_records, int64_t *total_out)
+{
+    if (!ctx || max_records < 0)
+        return WD_ERR_ARG;
+    if (bind_device(ctx))
+        return WD_ERR_HIP;
+    unsigned long long total = 0;
+    WD_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    WD_HIP(ctx, hipMemcpy(&total, ctx->d_hit_count, sizeof(total), hipMemcpyDeviceToHost));
+    if (total_out)
+        *total_out = (int64_t)total;
+    int64_t n = std::min<int64_t>((int64_t)total, std::min<int64_t>(max_records, ctx->hit_cap));
+    if (n > 0 && out_host)
+        WD_HIP(ctx, hipMemcpy(out_host, ctx->d_hits, (size_t)n * sizeof(wd_hit), hipMemcpyDeviceToHost));
+    return WD_OK;
+}
+
+int wd_profile_get(wd_ctx *ctx, double *total_ms, int64_t *launches)
+{
+    if (!ctx)
+        return WD_ERR_ARG;
+    if (bind_device(ctx))
+        return WD_ERR_HIP;
+    drain_events(ctx);
+    if (total_ms)
+        *total_ms = ctx->prof_ms;
+    if (launches)
+        *launches = ctx->prof_launches;
+    return WD_OK;
+}
+
+int wd_profile_reset(wd_ctx *ctx)
+{
+    if (!ctx)
+        return WD_ERR_ARG;
+    if (bind_device(ctx))
+        return WD_ERR_HIP;
+    drain_events(ctx);
+    ctx->prof_ms = 0.0;
+    ctx->prof_launches = 0;
+    return WD_OK;
+}
+
+// ---- RCCL ----------------------------------------------------------------------------
+int wd_comm_unique_id(void *out128)
+{
+    std::string err;
+    if (!out128 || !rccl_load(err))
+        return WD_ERR_COMM;
+    return g_rccl.GetUniqueId(out128) == 0 ? WD_OK : WD_ERR_COMM;
+}
+
+int wd_comm_init(wd_ctx *ctx, int rank, int world, const void *id128)
+{
+    if (!ctx || !id128 || world < 1 || rank < 0 || rank >= world)
+        return WD_ERR_ARG;
+    std::string err;
+    if (!rccl_load(err))
+        return fail(ctx, WD_ERR_COMM, err);
+    if (bind_device(ctx))
+        return WD_ERR_HIP;
+    if (ctx->comm) {
+        g_rccl.CommDestroy(ctx->comm);
+        ctx->comm = nullptr;
+    }
+    Id128 id;
+    memcpy(id.b, id128, WD_UNIQUE_ID_BYTES);
+    int rc = g_rccl.CommInitRank(&ctx->comm, world, id, rank);
+    if (rc != 0)
+        return fail(ctx, WD_ERR_COMM, std::string("ncclCommInitRank: ") +
+                                          (g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "?"));
+    return WD_OK;
+}
+
+int wd_allreduce_counts(wd_ctx *ctx, int64_t *buf_dev, size_t n)
+{
+    if (!ctx || (!buf_dev && n))
+        return WD_ERR_ARG;
+    if (!ctx->comm)
+        return fail(ctx, WD_ERR_STATE, "wd_comm_init has not been called");
+    if (bind_device(ctx))
+        return WD_ERR_HIP;
+    // ncclInt64 = 4, ncclSum = 0
+    int rc = g_rccl.AllReduce(buf_dev, buf_dev, n, 4, 0, ctx->comm, ctx->stream);
+    if (rc != 0)
+        return fail(ctx, WD_ERR_COMM, std::string("ncclAllReduce: ") +
+                                          (g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "?"));
+    return WD_OK;
+}
+
+int wd_comm_destroy(wd_ctx *ctx)
+{
+    if (!ctx)
+        return WD_ERR_ARG;
+    if (ctx->comm && g_rccl.CommDestroy) {
+        (void)hipStreamSynchronize(ctx->stream);
+        g_rccl.CommDestroy(ctx->comm);
+    }
+    ctx->comm = nullptr;
+    return WD_OK;
+}
+
+// ---- synthetic data ------------------------------------------------------------------
+static uint64_t synth_tile_key(const wd_synth_spec *s, int lane, int tile, uint64_t salt)
+{
+    return mix64(s->seed * K_SEED + (uint64_t)lane * K_LANE + (uint64_t)tile * K_TILE + salt);
+}
+
+int wd_synth_plane(wd_ctx *ctx, uint8_t *dst_dev, const wd_synth_spec *spec, int lane, int tile, int cycle)
+{
+    if (!ctx || !dst_dev || !spec || spec->n_clusters < 0)
+        return WD_ERR_ARG;
+    if (bind_device(ctx))
+        return WD_ERR_HIP;
+    SynthPlaneArgs a;
+    a.dst = dst_dev;
+    a.n = spec->n_clusters;
+    a.row = spec->row;
+    a.key_here = synth_tile_key(spec, lane, tile, (uint64_t)(cycle + 1) * K_CYCLE);
+    a.key_next = synth_tile_key(spec, lane, tile, (uint64_t)(cycle + 2) * K_CYCLE);
+    a.key_plant = synth_tile_key(spec, lane, tile, SALT_PLANT);
+    a.nocall = spec->nocall_per_64k;
+    a.plant = spec->plant_per_64k;
+    a.cycle = cycle;
+    if (a.n == 0)
+        return WD_OK;
+    unsigned blocks = (unsigned)std::min<int64_t>((a.n + kBlock - 1) / kBlock, 256 * 16);
+    hipLaunchKernelGGL(k_synth_plane, dim3(blocks), dim3(kBlock), 0, ctx->stream, a);
+    WD_HIP(ctx, hipGetLastError());
+    return WD_OK;
+}
+
+int wd_synth_filter(wd_ctx *ctx, uint8_t *dst_dev, const wd_synth_spec *spec, int lane, int tile)
+{
+    if (!ctx || !dst_dev || !spec || spec->n_clusters < 0)
+        return WD_ERR_ARG;
+    if (bind_device(ctx))
+        return WD_ERR_HIP;
+    SynthFilterArgs a;
+    a.dst = dst_dev;
+    a.n = spec->n_clusters;
+    a.key = synth_tile_key(spec, lane, tile, SALT_FILTER);
+    a.pass = spec->pass_per_64k;
+    a.noise = spec->filter_noise;
+    a.dead = spec->tile_dead;
+    if (a.n == 0)
+        return WD_OK;
+    unsigned blocks = (unsigned)std::min<int64_t>((a.n + kBlock - 1) / kBlock, 256 * 16);
+    hipLaunchKernelGGL(k_synth_filter, dim3(blocks), dim3(kBlock), 0, ctx->stream, a);
+    WD_HIP(ctx, hipGetLastError());
+    return WD_OK;
+}
+
+}  // extern "C"

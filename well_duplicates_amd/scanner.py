@@ -1,0 +1,293 @@
+"""Python face of the device scan path (thin: everything heavy is in libwelldup.so).
+
+`Scanner` wraps one `wd_ctx` (one GPU).  `TileBatch` keeps the BCL planes and filter bytes
+of a list of tiles resident in HBM in the layout the kernels like best: one slab
+[tile][cycle][N padded to 256 B], so consecutive cycle planes of a tile are a constant
+stride apart and every plane starts 256-byte aligned.
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import Iterable, List, Optional, Sequence
+
+import numpy as np
+
+from . import _lib
+from ._lib import MODE_EQ, MODE_HAMMING, MODE_LEVENSHTEIN, INVALID_TARGET  # noqa: F401
+
+PLANE_ALIGN = 256
+
+
+def compare_mode(edit_distance: int, hamming: bool):
+    """Map the reference's -e / --hamming flags (count_well_duplicates.py:200, :258) to
+    (mode, k).  -e 0 is string equality under either metric."""
+    if edit_distance == 0:
+        return MODE_EQ, 0
+    return (MODE_HAMMING if hamming else MODE_LEVENSHTEIN), int(edit_distance)
+
+
+def _raise(lib, ctx, rc: int):
+    detail = lib.wd_last_error(ctx).decode() if ctx else ""
+    msg = "%s%s" % (lib.wd_strerror(rc).decode(), (": " + detail) if detail else "")
+    if rc == _lib.ERR_INDEX:
+        raise IndexError(msg)            # bcl_direct_reader.py:186-192
+    if rc == _lib.ERR_EMPTY_LEVEL:
+        raise AssertionError(msg)        # count_well_duplicates.py:249
+    if rc == _lib.ERR_ARG:
+        raise ValueError(msg)
+    if rc == _lib.ERR_NOMEM:
+        raise MemoryError(msg)
+    raise RuntimeError(msg)
+
+
+class Scanner:
+    """One GPU context: resident targets + scan calls."""
+
+    def __init__(self, device: int = -1):
+        self._lib = _lib.load()
+        self._ctx = self._lib.wd_create(device)
+        if not self._ctx:
+            rc = self._lib.wd_create_status()
+            raise RuntimeError("wd_create(%d) failed: %s" % (device, self._lib.wd_strerror(rc).decode()))
+        self.T = 0
+        self.levels = 0
+        self._owned = set()
+
+    # ------------------------------------------------------------------ plumbing
+    def _ck(self, rc: int):
+        if rc != _lib.OK:
+            _raise(self._lib, self._ctx, rc)
+
+    def close(self):
+        if self._ctx:
+            for p in list(self._owned):
+                self._lib.wd_free(self._ctx, p)
+            self._owned.clear()
+            self._lib.wd_destroy(self._ctx)
+            self._ctx = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_option(self, name: str, value: int):
+        self._ck(self._lib.wd_set_option(self._ctx, name.encode(), int(value)))
+
+    def get_option(self, name: str) -> int:
+        v = ctypes.c_int64()
+        self._ck(self._lib.wd_get_option(self._ctx, name.encode(), ctypes.byref(v)))
+        return v.value
+
+    def set_stream(self, hip_stream: Optional[int]):
+        self._ck(self._lib.wd_set_stream(self._ctx, ctypes.c_void_p(hip_stream or 0)))
+
+    def synchronize(self):
+        self._ck(self._lib.wd_synchronize(self._ctx))
+
+    def malloc(self, nbytes: int) -> int:
+        p = ctypes.c_void_p()
+        self._ck(self._lib.wd_malloc(self._ctx, int(nbytes), ctypes.byref(p)))
+        self._owned.add(p.value)
+        return p.value
+
+    def free(self, ptr: int):
+        if ptr in self._owned:
+            self._owned.discard(ptr)
+            self._ck(self._lib.wd_free(self._ctx, ctypes.c_void_p(ptr)))
+
+    def h2d(self, dst: int, arr: np.ndarray):
+        arr = np.ascontiguousarray(arr)
+        self._ck(self._lib.wd_memcpy_h2d(self._ctx, ctypes.c_void_p(dst),
+                                         arr.ctypes.data_as(ctypes.c_void_p), arr.nbytes))
+
+    def d2h(self, src: int, nbytes: int, dtype=np.uint8) -> np.ndarray:
+        out = np.empty(int(nbytes) // np.dtype(dtype).itemsize, dtype=dtype)
+        self._ck(self._lib.wd_memcpy_d2h(self._ctx, out.ctypes.data_as(ctypes.c_void_p),
+                                         ctypes.c_void_p(src), out.nbytes))
+        return out
+
+    def memset(self, dst: int, value: int, nbytes: int):
+        self._ck(self._lib.wd_memset(self._ctx, ctypes.c_void_p(dst), value, int(nbytes)))
+
+    # ------------------------------------------------------------------ targets
+    def set_targets(self, centre, lvl_off, nbr):
+        """CSR as AllTargets.to_csr(): centre[T], lvl_off[T, levels+1], nbr[P] (int32)."""
+        centre = np.ascontiguousarray(centre, dtype=np.int32)
+        lvl_off = np.ascontiguousarray(lvl_off, dtype=np.int32)
+        nbr = np.ascontiguousarray(nbr, dtype=np.int32)
+        if lvl_off.ndim != 2 or lvl_off.shape[0] != centre.shape[0]:
+            raise ValueError("lvl_off must be [T, levels+1]")
+        T, levels = centre.shape[0], lvl_off.shape[1] - 1
+        if T and int(lvl_off[:, -1].max()) > nbr.shape[0]:
+            raise ValueError("lvl_off points past the end of nbr")
+        self._ck(self._lib.wd_set_targets(
+            self._ctx, T, levels, centre.ctypes.data_as(ctypes.c_void_p),
+            lvl_off.ctypes.data_as(ctypes.c_void_p), nbr.ctypes.data_as(ctypes.c_void_p)))
+        self.T, self.levels = T, levels
+
+    # ------------------------------------------------------------------ scan
+    @staticmethod
+    def _tables(planes, filters, L):
+        n_tiles = len(filters)
+        flat = [int(p) for tile in planes for p in tile]
+        if len(flat) != n_tiles * L:
+            raise ValueError("planes must hold n_tiles x L pointers")
+        pt = (ctypes.c_void_p * max(1, len(flat)))(*flat)
+        ft = (ctypes.c_void_p * max(1, n_tiles))(*[int(f) for f in filters])
+        return pt, ft
+
+    def count_tiles(self, planes: Sequence[Sequence[int]], filters: Sequence[int], n_clusters: int,
+                    mode: int, k: int, per_target: bool = False, tables=None, L=None):
+        """Synchronous scan of n_tiles tiles.
+
+        planes[i][c]: device address of tile i's c-th scanned cycle plane (N bytes);
+        filters[i]: device address of its filter bytes.  Returns (blocks, per_target):
+        blocks int64 [n_tiles, 1 + 5*levels] as documented in include/welldup.h;
+        per_target uint32 [n_tiles, T, levels] or None.
+        """
+        n_tiles = len(filters)
+        if L is None:
+            L = len(planes[0]) if n_tiles else 0
+        pt, ft = tables if tables is not None else self._tables(planes, filters, L)
+        blocks = np.zeros((n_tiles, 1 + 5 * self.levels), dtype=np.int64)
+        pto = np.zeros((n_tiles, self.T, self.levels), dtype=np.uint32) if per_target else None
+        self._ck(self._lib.wd_count_tiles(
+            self._ctx, n_tiles, L, mode, k, pt, ft, int(n_clusters),
+            blocks.ctypes.data_as(ctypes.c_void_p),
+            pto.ctypes.data_as(ctypes.c_void_p) if per_target else None))
+        return blocks, pto
+
+    def scan_async(self, tables, n_tiles: int, L: int, n_clusters: int, mode: int, k: int,
+                   out_tile_dev: int, out_per_target_dev: Optional[int] = None):
+        pt, ft = tables
+        self._ck(self._lib.wd_scan_async(
+            self._ctx, n_tiles, L, mode, k, pt, ft, int(n_clusters),
+            ctypes.c_void_p(out_tile_dev), ctypes.c_void_p(out_per_target_dev or 0)))
+
+    def scan_status(self):
+        self._ck(self._lib.wd_scan_status(self._ctx))
+
+    # ------------------------------------------------------------------ dup log / profile
+    def hitlog_enable(self, capacity: int):
+        self._ck(self._lib.wd_hitlog_enable(self._ctx, int(capacity)))
+
+    def hitlog_fetch(self, max_records: int):
+        buf = (_lib.Hit * max(1, max_records))()
+        total = ctypes.c_int64()
+        self._ck(self._lib.wd_hitlog_fetch(self._ctx, buf, max_records, ctypes.byref(total)))
+        n = min(total.value, max_records)
+        recs = np.frombuffer(buf, dtype=np.dtype([("tile", "<i4"), ("target", "<i4"),
+                                                  ("slot", "<i4"), ("dist", "<i4")]), count=n).copy()
+        return recs, total.value
+
+    def profile_get(self):
+        ms = ctypes.c_double()
+        n = ctypes.c_int64()
+        self._ck(self._lib.wd_profile_get(self._ctx, ctypes.byref(ms), ctypes.byref(n)))
+        return ms.value, n.value
+
+    def profile_reset(self):
+        self._ck(self._lib.wd_profile_reset(self._ctx))
+
+    # ------------------------------------------------------------------ multi-GPU
+    def comm_unique_id(self) -> bytes:
+        buf = ctypes.create_string_buffer(_lib.UNIQUE_ID_BYTES)
+        rc = self._lib.wd_comm_unique_id(buf)
+        if rc != _lib.OK:
+            _raise(self._lib, None, rc)
+        return buf.raw
+
+    def comm_init(self, rank: int, world: int, unique_id: bytes):
+        assert len(unique_id) == _lib.UNIQUE_ID_BYTES
+        self._ck(self._lib.wd_comm_init(self._ctx, rank, world, unique_id))
+
+    def allreduce_counts(self, buf_dev: int, n: int):
+        self._ck(self._lib.wd_allreduce_counts(self._ctx, ctypes.c_void_p(buf_dev), n))
+
+    def comm_destroy(self):
+        self._ck(self._lib.wd_comm_destroy(self._ctx))
+
+    # ------------------------------------------------------------------ synthetic data
+    def _spec_c(self, spec, tile: int):
+        return _lib.SynthSpecC(spec.seed, spec.n_clusters, spec.row, spec.nocall_per_64k,
+                               spec.pass_per_64k, spec.plant_per_64k, int(spec.filter_noise),
+                               int(int(tile) in tuple(int(t) for t in spec.dead_tiles)))
+
+    def synth_plane(self, dst: int, spec, lane: int, tile: int, cycle: int):
+        s = self._spec_c(spec, tile)
+        self._ck(self._lib.wd_synth_plane(self._ctx, ctypes.c_void_p(dst), ctypes.byref(s),
+                                          int(lane), int(tile), int(cycle)))
+
+    def synth_filter(self, dst: int, spec, lane: int, tile: int):
+        s = self._spec_c(spec, tile)
+        self._ck(self._lib.wd_synth_filter(self._ctx, ctypes.c_void_p(dst), ctypes.byref(s),
+                                           int(lane), int(tile)))
+
+
+class TileBatch:
+    """BCL planes + filter bytes of a list of tiles, resident in HBM.
+
+    Layout: planes[tile][cycle][N_pad] and filters[tile][N_pad], N_pad = N rounded up to
+    256 bytes.  Fill with `fill_synthetic` (device generator) or `upload_tile` (host bytes).
+    """
+
+    def __init__(self, scanner: Scanner, n_tiles: int, L: int, n_clusters: int):
+        self.sc = scanner
+        self.n_tiles, self.L, self.N = n_tiles, L, n_clusters
+        self.n_pad = (n_clusters + PLANE_ALIGN - 1) // PLANE_ALIGN * PLANE_ALIGN
+        self.plane_bytes = n_tiles * L * self.n_pad
+        self.filter_bytes = n_tiles * self.n_pad
+        self.d_planes = scanner.malloc(max(1, self.plane_bytes))
+        self.d_filters = scanner.malloc(max(1, self.filter_bytes))
+        self.tables = Scanner._tables(self.plane_ptrs(), self.filter_ptrs(), L)
+
+    def plane_ptr(self, tile: int, cycle: int) -> int:
+        return self.d_planes + (tile * self.L + cycle) * self.n_pad
+
+    def filter_ptr(self, tile: int) -> int:
+        return self.d_filters + tile * self.n_pad
+
+    def plane_ptrs(self) -> List[List[int]]:
+        return [[self.plane_ptr(i, c) for c in range(self.L)] for i in range(self.n_tiles)]
+
+    def filter_ptrs(self) -> List[int]:
+        return [self.filter_ptr(i) for i in range(self.n_tiles)]
+
+    def fill_synthetic(self, spec, lane_tile: Sequence, cycles: Sequence[int]):
+        """lane_tile: [(lane, tile number)] per batch slot; cycles: the L 0-based cycles."""
+        assert len(lane_tile) == self.n_tiles and len(cycles) == self.L
+        assert spec.n_clusters == self.N
+        for i, (lane, tile) in enumerate(lane_tile):
+            self.sc.synth_filter(self.filter_ptr(i), spec, lane, tile)
+            for c, cyc in enumerate(cycles):
+                self.sc.synth_plane(self.plane_ptr(i, c), spec, lane, tile, cyc)
+        self.sc.synchronize()
+
+    def upload_tile(self, slot: int, planes: Iterable[np.ndarray], filt: np.ndarray):
+        for c, p in enumerate(planes):
+            assert p.shape[0] == self.N
+            self.sc.h2d(self.plane_ptr(slot, c), np.ascontiguousarray(p, dtype=np.uint8))
+        assert filt.shape[0] == self.N
+        self.sc.h2d(self.filter_ptr(slot), np.ascontiguousarray(filt, dtype=np.uint8))
+
+    def download_plane(self, slot: int, cycle: int) -> np.ndarray:
+        return self.sc.d2h(self.plane_ptr(slot, cycle), self.N)
+
+    def download_filter(self, slot: int) -> np.ndarray:
+        return self.sc.d2h(self.filter_ptr(slot), self.N)
+
+    def count(self, mode: int, k: int, per_target: bool = False):
+        return self.sc.count_tiles(None, self.filter_ptrs(), self.N, mode, k, per_target,
+                                   tables=self.tables, L=self.L)
+
+    def free(self):
+        self.sc.free(self.d_planes)
+        self.sc.free(self.d_filters)

@@ -1,0 +1,148 @@
+"""Targets-file model: host-side mirror of the reference's target.py for the scan path.
+
+Same names, argument meaning and error behaviour as the reference
+(target.py:6-40 `load_targets`, :42-106 `AllTargets`, :108-144 `Target`), so the
+reference's own test_target.py assertions apply unchanged (tests/test_targets.py).
+What is new is `AllTargets.to_csr()`: the ragged per-level neighbour lists flattened
+into the CSR arrays the device keeps resident (level lists are ragged,
+never a dense [T, 6*level] tensor).
+
+File format: a record is one line holding a single integer
+(the centre well, no comma) followed by one comma-separated line per level.  A line
+without a comma starts the next record.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+
+class Target:
+    """One centre well plus its per-level neighbour wells: [[c], [lvl 1 ...], [lvl 2 ...]]."""
+
+    __slots__ = ("coords",)
+
+    def __init__(self, coords):
+        # target.py:113 - the centre line must hold exactly one integer
+        assert len(coords[0]) == 1, "Centre of target must be a single int, not " + str(coords)
+        self.coords = coords
+
+    def get_indices(self, level=None):
+        if level is None:
+            return [w for ring in self.coords for w in ring]
+        return self.coords[level]
+
+    def get_centre(self):
+        return self.coords[0][0]
+
+    def get_levels(self):
+        """Number of lines in the record, the centre line included."""
+        return len(self.coords)
+
+    def get_level_from_index(self, index):
+        for lev, ring in enumerate(self.coords):
+            if index in ring:
+                return lev
+        return None
+
+
+class AllTargets:
+    """Ordered collection of Target objects (file order == iteration order, target.py:59-61)."""
+
+    def __init__(self):
+        self._by_centre = {}
+        self._wells = {}          # well index -> [Target, ...] in insertion order
+        self.levels = None
+
+    def __len__(self):
+        return len(self._by_centre)
+
+    def __iter__(self):
+        return iter(self._by_centre.values())
+
+    def get_target_by_centre(self, centre):
+        return self._by_centre[centre]
+
+    def add_target(self, coords):
+        t = Target(coords)
+        # target.py:72 - a centre may appear once only
+        assert t.get_centre() not in self._by_centre
+        # target.py:75-78 - every record has the same number of lines
+        if self.levels is None:
+            self.levels = t.get_levels()
+        else:
+            assert self.levels == t.get_levels()
+        self._by_centre[t.get_centre()] = t
+        for w in t.get_indices():
+            self._wells.setdefault(w, []).append(t)
+
+    def get_all_indices(self, level=None):
+        """All well indices held; level=0 centres only, level=n that ring only (with repeats)."""
+        if level == 0:
+            return list(self._by_centre.keys())
+        if level is None:
+            return list(self._wells.keys())
+        return [w for t in self for w in t.get_indices(level)]
+
+    def get_from_index(self, index):
+        return [(t, t.get_level_from_index(index)) for t in self._wells.get(index, [])]
+
+    # ---------------------------------------------------------------- device layout
+    def to_csr(self, levels=None):
+        """Flatten rings 1..levels of every target, in file order.
+
+        Returns (centre[T] int32, lvl_off[T, levels+1] int32, nbr[P] int32) where the
+        neighbours of target t at level l (1-based, as `Target.get_indices(l)`) are
+        nbr[lvl_off[t, l-1] : lvl_off[t, l]].  Offsets are absolute into nbr.
+        """
+        have = (self.levels or 1) - 1
+        if levels is None:
+            levels = have
+        if levels > have:
+            raise ValueError("targets file holds %d levels, %d requested" % (have, levels))
+        T = len(self)
+        centre = np.empty(T, dtype=np.int64)
+        lvl_off = np.zeros((T, levels + 1), dtype=np.int64)
+        flat = []
+        pos = 0
+        for i, t in enumerate(self):
+            centre[i] = t.get_centre()
+            lvl_off[i, 0] = pos
+            for lev in range(1, levels + 1):
+                ring = t.coords[lev]
+                flat.extend(ring)
+                pos += len(ring)
+                lvl_off[i, lev] = pos
+        nbr = np.asarray(flat, dtype=np.int64) if flat else np.zeros(0, dtype=np.int64)
+        for name, arr in (("centre", centre), ("neighbour", nbr)):
+            if arr.size and (arr.min() < -(2 ** 31) or arr.max() >= 2 ** 31):
+                raise OverflowError("%s index does not fit int32" % name)
+        if pos >= 2 ** 31:
+            raise OverflowError("too many neighbour slots for int32 offsets")
+        return (centre.astype(np.int32), lvl_off.astype(np.int32), nbr.astype(np.int32))
+
+
+def load_targets(filename, levels=None, limit=None):
+    """Parse a targets file.
+
+    levels: number of lines per record to keep, the centre line included (so the CLI
+            passes `-l` + 1, count_well_duplicates.py:202-204); None keeps all.
+    limit:  stop after this many targets (falsy = no limit).
+
+    Errors as the reference: a blank line raises ValueError (int('')); records of
+    differing length or a repeated centre raise AssertionError.
+    """
+    all_targets = AllTargets()
+    pending = None
+    with open(filename, "r") as fh:
+        lines = [ln.rstrip() for ln in fh]
+    lines.append("")              # sentinel: flushes the last record (target.py:25)
+    for ln in lines:
+        if "," not in ln:
+            if pending:
+                all_targets.add_target(
+                    [[int(tok) for tok in rec.split(",")] for rec in pending[:levels]])
+                if limit and len(all_targets) == limit:
+                    break
+            pending = []
+        pending.append(ln)
+    return all_targets
