@@ -1,0 +1,226 @@
+#!/usr/bin/env python3
+"""bench.py - the headline benchmark: target x neighbour sequence compares per second.
+
+Workload (BASELINE.json configs[1], one per rank = weak scaling): one lane of a HiSeq-X style
+flowcell = 96 tiles x 2500 targets (prepare_cluster_indexes semantics, seed 13) x 5 levels,
+50 bp, HiSeq-4000 tile geometry (2743 x 1571 = 4 309 253 clusters/tile), synthetic BCL planes
+and filters generated on the device from the counter-based spec (well_duplicates_amd/synth.py:
+0.5 % no-calls, 70 % filter pass, 2 % planted near-duplicates).  Rank r scans lane r+1.
+
+A "step" is one pass of the scan path over the rank's 96 resident tiles (all kernels of
+wd_scan_async) plus, for N > 1, the one int64 all-reduce of the [lanes*tiles, 1+5*levels]
+counter block.  Inputs are resident in HBM before the timed region.  One unit of work is one
+performed compare = one unit of the reference report's `Wells` column
+(count_well_duplicates.py:93), read back from the device's own counters.
+
+Extra objects on the JSON line:
+  roofline      HBM roofline of the dominant kernel (k_scan): algorithmic bytes
+                B = C*(L+4) + Tv*(L+5) + 8*(1+5*levels)*tiles per launch over the
+                kernel's mean duration, measured with HIP events on the launch stream.
+  cpu_baseline  the C oracle (oracle/welldup_oracle.c, -O3, OpenMP over tiles) on a bounded
+                sample of the same tiles, on this box's host cores.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--tiles", type=int, default=96, help="tiles per rank (one lane)")
+    ap.add_argument("--targets", type=int, default=2500)
+    ap.add_argument("--levels", type=int, default=5)
+    ap.add_argument("--bases", type=int, default=50)
+    ap.add_argument("--mode", default="eq", choices=["eq", "hamming", "levenshtein"])
+    ap.add_argument("-k", type=int, default=0, help="distance threshold (hamming / levenshtein)")
+    ap.add_argument("--no-early-exit", action="store_true",
+                    help="full gather: read all L bytes of every neighbour")
+    ap.add_argument("--cpu-tiles", type=int, default=8, help="tiles in the CPU-baseline sample")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--profile-steps", type=int, default=20)
+    ap.add_argument("--option", action="append", default=[], help="name=value scanner option")
+    return ap.parse_args()
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("launch with: python -m torch.distributed.run --nproc-per-node %d bench.py --gpus %d"
+                     % (args.gpus, args.gpus))
+        args.gpus = world
+
+    import torch
+    import torch.distributed as dist
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from well_duplicates_amd import synth, workload
+    from well_duplicates_amd.scanner import Scanner, TileBatch, MODE_EQ, MODE_HAMMING, MODE_LEVENSHTEIN
+
+    mode = {"eq": MODE_EQ, "hamming": MODE_HAMMING, "levenshtein": MODE_LEVENSHTEIN}[args.mode]
+    k = 0 if args.mode == "eq" else args.k
+    rows, cols = workload.HISEQ4000_ROWS, workload.HISEQ4000_COLS
+    n_clusters = rows * cols
+    L, levels, T = args.bases, args.levels, args.targets
+    ncnt = 1 + 5 * levels
+
+    # ---- inputs: targets (replicated), this rank's lane of tiles (resident) -------------
+    t0 = time.time()
+    centre, lvl_off, nbr = workload.honeycomb_targets(rows, cols, T, levels, seed=13)
+    spec = synth.SynthSpec(seed=2, n_clusters=n_clusters, row=cols)
+    lane = rank + 1
+    tile_ids = [int(t) for t in workload.tiles_for_stype(workload.HISEQ_X)]
+    tile_ids = (tile_ids * ((args.tiles + len(tile_ids) - 1) // len(tile_ids)))[:args.tiles]
+    # repeated ids (only if --tiles > 96) get distinct lanes so no two tiles share data
+    lane_tile = [(lane + 8 * (i // 96), t) for i, t in enumerate(tile_ids)]
+
+    sc = Scanner(local_rank)
+    sc.set_stream(torch.cuda.current_stream().cuda_stream)
+    for opt in args.option:
+        name, val = opt.split("=")
+        sc.set_option(name, int(val))
+    if args.no_early_exit:
+        sc.set_option("early_exit", 0)
+    sc.set_targets(centre, lvl_off, nbr)
+    tb = TileBatch(sc, args.tiles, L, n_clusters)
+    tb.fill_synthetic(spec, lane_tile, list(range(L)))
+    setup_s = time.time() - t0
+
+    # global counter block: every rank owns rows [rank*tiles, (rank+1)*tiles)
+    block = torch.zeros((world * args.tiles, ncnt), dtype=torch.int64, device="cuda")
+    my_rows = block[rank * args.tiles:(rank + 1) * args.tiles]
+
+    def step():
+        if world > 1:
+            block.zero_()
+        sc.scan_async(tb.tables, args.tiles, L, n_clusters, mode, k, my_rows.data_ptr())
+        if world > 1:
+            dist.all_reduce(block)          # RCCL int64 sum over xGMI; rows are disjoint
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    sc.scan_status()
+    fence()
+    t_start = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t_start
+    sc.scan_status()
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+
+    counts = block.cpu().numpy()
+    compares_all = int(counts[:, 1:1 + levels].sum())          # sum of Wells over every rank
+    mine = counts[rank * args.tiles:(rank + 1) * args.tiles]
+    compares_rank = int(mine[:, 1:1 + levels].sum())
+    valid_rank = int(mine[:, 0].sum())
+    ms_per_step = elapsed / max(1, args.steps) * 1e3
+    value = compares_all / (elapsed / max(1, args.steps))
+
+    # ---- roofline of the dominant kernel: HIP events on the launch stream ----------------
+    sc.set_option("profile", 1)
+    sc.profile_reset()
+    for _ in range(args.profile_steps):
+        sc.scan_async(tb.tables, args.tiles, L, n_clusters, mode, k, my_rows.data_ptr())
+    kern_ms_total, launches = sc.profile_get()
+    sc.set_option("profile", 0)
+    kern_ms = kern_ms_total / max(1, launches)
+    b_alg = compares_rank * (L + 4) + valid_rank * (L + 5) + 8 * ncnt * args.tiles
+    achieved = b_alg / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0
+    traffic = None
+    tpath = os.path.join(REPO, "profiles", "traffic.json")
+    if os.path.exists(tpath):
+        try:
+            tj = json.load(open(tpath))
+            key = "%s_k%d_t%d_T%d_l%d_L%d_%s" % (args.mode, k, args.tiles, T, levels, L,
+                                                "full" if args.no_early_exit else "early")
+            traffic = tj.get(key, {}).get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+    roofline = {"bound": "hbm", "kernel": "k_scan", "achieved": round(achieved, 2),
+                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+                "traffic": traffic, "algorithmic_bytes_per_launch": b_alg,
+                "kernel_ms": round(kern_ms, 5), "launches_timed": launches,
+                "units_per_launch": compares_rank}
+
+    # ---- CPU baseline: the oracle on a bounded sample, rank 0 at N = 1 only --------------
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle import oracle
+        n_cpu = max(1, min(args.cpu_tiles, args.tiles))
+        cores = max(1, min(16, os.cpu_count() or 1, n_cpu))
+        planes = [[tb.download_plane(i, c) for c in range(L)] for i in range(n_cpu)]
+        filters = [tb.download_filter(i) for i in range(n_cpu)]
+        reps, t_cpu, out = 0, 0.0, None
+        t1 = time.perf_counter()
+        while t_cpu < 10.0 and reps < 50:
+            out = oracle.count_tiles_mt(planes, filters, centre, lvl_off, nbr, mode, k, cores)
+            reps += 1
+            t_cpu = time.perf_counter() - t1
+        cpu_compares = int(out[:, 1:1 + levels].sum())
+        # the sample doubles as an end-to-end check of the timed path
+        dev = mine[:n_cpu].copy()
+        dev[:, 1 + 3 * levels:1 + 4 * levels] = np.cumsum(dev[:, 1 + 3 * levels:1 + 4 * levels], axis=1)
+        dev[:, 1 + 4 * levels:] = np.cumsum(dev[:, 1 + 4 * levels:][:, ::-1], axis=1)[:, ::-1]
+        if not (dev == out).all():
+            raise SystemExit("bench: device counters differ from the CPU oracle on the sample tiles")
+        cpu = {"value": round(cpu_compares * reps / t_cpu, 1), "unit": "compares/s", "cores": cores,
+               "kind": "port",
+               "sample": "%d of the %d tiles (%d compares), C oracle -O3, OpenMP over tiles, %d passes in %.1f s; "
+                         "planes already decompressed in RAM (the reference also gunzips and builds Python strings)"
+                         % (n_cpu, args.tiles, cpu_compares, reps, t_cpu),
+               "parity_checked_tiles": n_cpu}
+
+    if rank == 0:
+        line = {
+            "metric": "target x neighbour seq-compares/sec (whole node)",
+            "value": round(value, 1), "unit": "compares/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 5), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+            "config": {"workload": "1 lane x %d tiles x %d targets x %d levels, %d bp per GPU "
+                                   "(BASELINE configs[1]; N GPUs = N lanes)" % (args.tiles, T, levels, L),
+                       "mode": args.mode, "k": k, "early_exit": not args.no_early_exit,
+                       "clusters_per_tile": n_clusters, "compares_per_step": compares_all,
+                       "valid_targets_per_rank": valid_rank, "parallelism": "tiles sharded, %d rank(s)" % world,
+                       "setup_s": round(setup_s, 1)},
+            "roofline": roofline,
+            "cpu_baseline": cpu,
+        }
+        print(json.dumps(line))
+    tb.free()
+    sc.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

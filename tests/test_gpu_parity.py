@@ -1,0 +1,307 @@
+"""GPU parity tests: the HIP path, called through the C ABI (libwelldup.so via ctypes),
+against the CPU oracle and the golden fixtures made from the unmodified reference.
+
+Bar: bit-exact (integer work).  Everything here needs a real MI355X: `-m gpu`.
+"""
+import numpy as np
+import pytest
+
+from helpers import (FIXTURES, MODE_ID, blocks_to_reference, compact_tile, fixture_targets,
+                     lane_dupl_from, load_fixture, run_cycles)
+from oracle import oracle
+from well_duplicates_amd import cluster_indexes, synth
+from well_duplicates_amd.scanner import INVALID_TARGET, Scanner, TileBatch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def sc():
+    s = Scanner(0)
+    yield s
+    s.close()
+
+
+def device_lane_dupl(pt_tile, lvl_off):
+    """uint32 [T, levels] (INVALID rows skipped) + ring sizes -> reference lane_dupl entry."""
+    lens = np.diff(lvl_off, axis=1)
+    out = []
+    for t in range(pt_tile.shape[0]):
+        if pt_tile.shape[1] and pt_tile[t, 0] == INVALID_TARGET:
+            assert (pt_tile[t] == INVALID_TARGET).all()
+            continue
+        out.append([[int(pt_tile[t, l]), int(lens[t, l])] for l in range(pt_tile.shape[1])])
+    return out
+
+
+# ---------------------------------------------------------------------------------------
+def test_synth_device_matches_numpy(sc):
+    for spec, lane, tile in (
+            (synth.SynthSpec(seed=3, n_clusters=200003, row=517, plant_per_64k=9000,
+                             nocall_per_64k=1500, filter_noise=True), 2, 1203),
+            (synth.SynthSpec(seed=1, n_clusters=70001, row=1571), 1, 1101),
+            (synth.SynthSpec(seed=5, n_clusters=4096, row=64, dead_tiles=(2205,)), 8, 2205)):
+        cycles = [0, 1, 2, 50, 126, 127, 128, 149]
+        tb = TileBatch(sc, 1, len(cycles), spec.n_clusters)
+        tb.fill_synthetic(spec, [(lane, tile)], cycles)
+        for c, cyc in enumerate(cycles):
+            assert (tb.download_plane(0, c) == synth.plane_bytes(spec, lane, tile, cyc)).all(), cyc
+        assert (tb.download_filter(0) == synth.filter_bytes(spec, lane, tile)).all()
+        tb.free()
+
+
+@pytest.mark.parametrize("name", FIXTURES)
+def test_golden_fixtures(sc, name):
+    """Every golden run of the reference, reproduced on the device: per-target dup counts
+    (the reference's lane_dupl), the per-tile tally block, and the duplicate log."""
+    fx = load_fixture(name)
+    spec = synth.spec_from_dict(fx["spec"])
+    targets, (centre, lvl_off, nbr) = fixture_targets(name)
+    levels = fx["levels"]
+    sc.set_targets(centre, lvl_off, nbr)
+    slots = [(lane, tile) for lane in fx["lanes"] for tile in fx["tiles"]]
+    batches = {}
+    for run in fx["runs"]:
+        cycles = tuple(run_cycles(run))
+        if cycles not in batches:
+            tb = TileBatch(sc, len(slots), len(cycles), spec.n_clusters)
+            tb.fill_synthetic(spec, [(l, int(t)) for l, t in slots], cycles)
+            batches[cycles] = tb
+        tb = batches[cycles]
+        mode, k = MODE_ID[run["mode"]], run["k"]
+        sc.hitlog_enable(100000)
+        blocks, pt = tb.count(mode, k, per_target=True)
+        hits, total = sc.hitlog_fetch(100000)
+        sc.hitlog_enable(0)
+        want_by_lane = {int(r["lane"]): r["lane_dupl"] for r in run["lanes"]}
+        n_dups = 0
+        for i, (lane, tile) in enumerate(slots):
+            got = device_lane_dupl(pt[i], lvl_off)
+            assert got == want_by_lane[lane][tile], (name, run["flags"], lane, tile)
+            # tally block vs the oracle's reduction of the same per-target data
+            valid = (pt[i][:, 0] != INVALID_TARGET).astype(np.uint8) if levels else None
+            d = np.where(pt[i] == INVALID_TARGET, 0, pt[i]).astype(np.int32)
+            ref_block = oracle.tally_tile(valid, d, np.diff(lvl_off, axis=1).astype(np.int32))
+            assert (blocks_to_reference(blocks[i], levels) == ref_block).all()
+            n_dups += int(d.sum())
+        # duplicate log: one record per duplicate, with the reference's distances
+        assert total == n_dups == len(run["dup_log"]) // 3 or "-q" in run["flags"]
+        if "-q" not in run["flags"]:
+            want = []
+            log = run["dup_log"]
+            for j in range(0, len(log), 3):
+                c = int(log[j].split(":")[0].split()[-1])
+                w = int(log[j + 1].split(":")[0].split()[-1])
+                dist = int(log[j + 2].split(":")[1])
+                want.append((c, w, dist))
+            got = sorted((int(centre[h["target"]]), int(nbr[h["slot"]]), int(h["dist"])) for h in hits)
+            assert got == sorted(want)
+    for tb in batches.values():
+        tb.free()
+
+
+# ---------------------------------------------------------------------------------------
+def _random_case(rng, n_clusters, T, levels, ring=8):
+    """Random ragged targets on a small tile (neighbours near the centre so plants hit)."""
+    centres = rng.choice(n_clusters, size=T, replace=False)
+    lvl_off = np.zeros((T, levels + 1), dtype=np.int32)
+    nbr = []
+    pos = 0
+    for t, c in enumerate(centres):
+        lvl_off[t, 0] = pos
+        for l in range(levels):
+            n = int(rng.integers(1, ring + 1))
+            cand = c + rng.integers(-3, 4, size=n) + rng.integers(-2, 3, size=n) * 97
+            cand = np.clip(cand, 0, n_clusters - 1)
+            nbr.extend(cand.tolist())
+            pos += n
+            lvl_off[t, l + 1] = pos
+    return centres.astype(np.int32), lvl_off, np.asarray(nbr, dtype=np.int32)
+
+
+@pytest.mark.parametrize("L", [1, 2, 5, 9, 50, 64, 65, 100, 150])
+def test_all_modes_vs_oracle(sc, L):
+    """Equality, Hamming <= k and Levenshtein <= k for many k (incl. k < 0, k >= L), heavy
+    planting so that near-duplicates of every variant occur, ragged rings, repeated wells."""
+    rng = np.random.default_rng(100 + L)
+    spec = synth.SynthSpec(seed=20 + L, n_clusters=20011, row=97, plant_per_64k=30000,
+                           nocall_per_64k=3000, pass_per_64k=52000)
+    T, levels = 300, 4
+    centre, lvl_off, nbr = _random_case(rng, spec.n_clusters, T, levels)
+    sc.set_targets(centre, lvl_off, nbr)
+    cycles = list(range(3, 3 + L))
+    tb = TileBatch(sc, 2, L, spec.n_clusters)
+    tb.fill_synthetic(spec, [(1, 1101), (3, 2210)], cycles)
+    host = []
+    for i, (lane, tile) in enumerate([(1, 1101), (3, 2210)]):
+        host.append(compact_tile(spec, lane, tile, cycles, centre, nbr))
+    ks = {0: [0], 1: [-1, 0, 1, 2, 3, 7, L - 1, L, L + 5],
+          2: [-1, 0, 1, 2, 3, 4, 5, 6, 7, 9, 12, 13, 16, 17, L - 1, L, L + 3]}
+    for mode, klist in ks.items():
+        for k in klist:
+            if mode == 2 and 18 <= k < L:
+                continue
+            blocks, pt = tb.count(mode, k, per_target=True)
+            for i in range(2):
+                planes, filt, c2, n2, _ = host[i]
+                valid, dups, lens, _ = oracle.count_tile(planes, filt, c2, lvl_off, n2, mode, k)
+                want = np.where(valid[:, None] == 1, dups, -1)
+                got = pt[i].astype(np.int64)
+                got[got == INVALID_TARGET] = -1
+                assert (got == want).all(), (L, mode, k, i)
+                assert (blocks_to_reference(blocks[i], levels) == oracle.tally_tile(valid, dups, lens)).all()
+    tb.free()
+
+
+def test_kernel_variants_agree(sc):
+    """early_exit on/off, every batch shape, several targets_per_block, strided and
+    pointer-table plane layouts: identical counters."""
+    rng = np.random.default_rng(5)
+    spec = synth.SynthSpec(seed=77, n_clusters=30011, row=97, plant_per_64k=20000, nocall_per_64k=2000)
+    T, levels, L = 500, 5, 50
+    centre, lvl_off, nbr = _random_case(rng, spec.n_clusters, T, levels, ring=40)
+    sc.set_targets(centre, lvl_off, nbr)
+    tb = TileBatch(sc, 3, L, spec.n_clusters)
+    tb.fill_synthetic(spec, [(1, 1101), (1, 1102), (2, 1101)], list(range(L)))
+    base = {}
+    for mode, k in ((0, 0), (1, 2), (2, 2), (2, 5)):
+        base[(mode, k)] = tb.count(mode, k, per_target=True)
+    try:
+        for early in (0, 1):
+            for b1, b2 in ((2, 4), (3, 4), (4, 4), (4, 8), (8, 8)):
+                for tpb in (1, 4, 7, 64):
+                    sc.set_option("early_exit", early)
+                    sc.set_option("batch_first", b1)
+                    sc.set_option("batch_next", b2)
+                    sc.set_option("targets_per_block", tpb)
+                    for (mode, k), (bl, pt) in base.items():
+                        bl2, pt2 = tb.count(mode, k, per_target=True)
+                        assert (bl2 == bl).all() and (pt2 == pt).all(), (early, b1, b2, tpb, mode, k)
+        # pointer-table layout: planes in scrambled order with odd alignments
+        sc.set_option("early_exit", 1)
+        n = spec.n_clusters
+        slab = sc.malloc(3 * L * (n + 13) + 64)
+        ptrs = [[0] * L for _ in range(3)]
+        order = rng.permutation(3 * L)
+        for j, o in enumerate(order):
+            i, c = divmod(int(o), L)
+            ptrs[i][c] = slab + 1 + j * (n + 13)
+            sc.h2d(ptrs[i][c], tb.download_plane(i, c))
+        for (mode, k), (bl, pt) in base.items():
+            bl2, pt2 = sc.count_tiles(ptrs, tb.filter_ptrs(), n, mode, k, per_target=True)
+            assert (bl2 == bl).all() and (pt2 == pt).all()
+        sc.free(slab)
+    finally:
+        for name, v in (("early_exit", 1), ("batch_first", 4), ("batch_next", 8), ("targets_per_block", 8)):
+            sc.set_option(name, v)
+    tb.free()
+
+
+def test_errors_and_edges(sc):
+    spec = synth.SynthSpec(seed=2, n_clusters=5000, row=50)
+    tb = TileBatch(sc, 1, 4, spec.n_clusters)
+    tb.fill_synthetic(spec, [(1, 1101)], [0, 1, 2, 3])
+    centre = np.array([10, 20], np.int32)
+    # index == N: IndexError (bcl_direct_reader.py:186-192), nothing launched
+    sc.set_targets(centre, np.array([[0, 1], [1, 2]], np.int32), np.array([11, 5000], np.int32))
+    with pytest.raises(IndexError):
+        tb.count(0, 0)
+    sc.set_targets(centre, np.array([[0, 1], [1, 2]], np.int32), np.array([11, -1], np.int32))
+    with pytest.raises(IndexError):
+        tb.count(0, 0)
+    # a neighbour slot no target refers to is not range-checked
+    sc.set_targets(centre, np.array([[0, 1], [1, 2]], np.int32), np.array([11, 21, 999999], np.int32))
+    tb.count(0, 0)
+    # empty ring under a valid centre: AssertionError (count_well_duplicates.py:249)
+    filt = synth.filter_bytes(spec, 1, 1101)
+    good = int(np.flatnonzero(filt & 1)[0])
+    bad = int(np.flatnonzero((filt & 1) == 0)[0])
+    sc.set_targets(np.array([good], np.int32), np.array([[0, 1, 1]], np.int32), np.array([3], np.int32))
+    with pytest.raises(AssertionError):
+        tb.count(0, 0)
+    # ... but not under an invalid centre (:236-237 skips it first)
+    sc.set_targets(np.array([bad], np.int32), np.array([[0, 1, 1]], np.int32), np.array([3], np.int32))
+    blocks, pt = tb.count(0, 0, per_target=True)
+    assert blocks[0, 0] == 0 and (pt == INVALID_TARGET).all()
+    # argument errors
+    with pytest.raises(ValueError):
+        sc.set_targets(np.array([1], np.int32), np.array([[0, 2, 1]], np.int32), np.array([3, 4], np.int32))
+    with pytest.raises(ValueError):
+        sc.set_option("no_such_option", 1)
+    sc.set_targets(centre, np.array([[0, 1], [1, 2]], np.int32), np.array([11, 21], np.int32))
+    with pytest.raises(ValueError):
+        tb.count(5, 0)
+    # no targets / no tiles / no cycles
+    sc.set_targets(np.zeros(0, np.int32), np.zeros((0, 3), np.int32), np.zeros(0, np.int32))
+    blocks, _ = tb.count(0, 0)
+    assert blocks.shape == (1, 11) and (blocks == 0).all()
+    sc.set_targets(centre, np.array([[0, 1], [1, 2]], np.int32), np.array([11, 21], np.int32))
+    bl, _ = sc.count_tiles([], [], spec.n_clusters, 0, 0)
+    assert bl.shape == (0, 6)
+    tb0 = TileBatch(sc, 1, 0, spec.n_clusters)      # L = 0: every pair of empty strings matches
+    tb0.fill_synthetic(spec, [(1, 1101)], [])
+    bl, pt = tb0.count(1, 0, per_target=True)
+    v = filt[centre] & 1
+    assert bl[0, 0] == v.sum() and bl[0, 2] == v.sum()      # Dups == Wells == 1 per valid target
+    bl, _ = tb0.count(1, -1)
+    assert bl[0, 2] == 0
+    tb0.free()
+    tb.free()
+
+
+def test_fresh_context_requires_targets():
+    s = Scanner(0)
+    with pytest.raises(RuntimeError):
+        s.count_tiles([], [], 10, 0, 0)
+    s.close()
+
+
+# ---------------------------------------------------------------------------------------
+def test_production_shape_properties(sc):
+    """BASELINE config 1/2 shape (HiSeq-4000 tile geometry, 2500 targets, 5 levels, 50 bp)
+    on a few tiles: size-independent properties + one tile against the oracle."""
+    rows, cols = 2743, 1571
+    n = rows * cols
+    spec = synth.SynthSpec(seed=2, n_clusters=n, row=cols)
+    x, y = synth.honeycomb_pixels(rows, cols)
+    centres = cluster_indexes.sample_centres(n, 2500, 13)
+    tg = cluster_indexes.generate(x, y, centres, 5)
+    centre = np.array([c for c, _ in tg], np.int32)
+    lens = np.array([[len(r) for r in rings] for _, rings in tg], np.int32)
+    lvl_off = np.zeros((2500, 6), np.int32)
+    lvl_off[:, 1:] = np.cumsum(lens, axis=1)
+    lvl_off += np.concatenate([[0], np.cumsum(lens.sum(axis=1))[:-1]]).astype(np.int32)[:, None]
+    nbr = np.concatenate([np.concatenate(rings) for _, rings in tg]).astype(np.int32)
+    sc.set_targets(centre, lvl_off, nbr)
+    L, tiles = 50, [(1, 1101), (1, 1102), (1, 2228), (5, 1205)]
+    tb = TileBatch(sc, len(tiles), L, n)
+    tb.fill_synthetic(spec, tiles, list(range(L)))
+    res = {}
+    for mode, k in ((0, 0), (1, 2), (2, 2)):
+        bl, pt = tb.count(mode, k, per_target=True)
+        res[(mode, k)] = bl
+        sc.set_option("early_exit", 0)
+        bl_full, pt_full = tb.count(mode, k, per_target=True)      # full gather, same answer
+        sc.set_option("early_exit", 1)
+        assert (bl == bl_full).all() and (pt == pt_full).all()
+        bl_again, _ = tb.count(mode, k)                               # idempotent
+        assert (bl == bl_again).all()
+        for i, (lane, tile) in enumerate(tiles):
+            valid = synth.filter_bytes(spec, lane, tile, centre) & 1
+            assert bl[i, 0] == valid.sum()
+            assert (bl[i, 1:6] == (lens * valid[:, None]).sum(axis=0)).all()      # Wells
+            d = np.where(pt[i] == INVALID_TARGET, 0, pt[i]).astype(np.int64)
+            assert ((pt[i][:, 0] == INVALID_TARGET) == (valid == 0)).all()
+            assert (bl[i, 6:11] == d.sum(axis=0)).all()                            # Dups
+            assert (bl[i, 11:16] == (d > 0).sum(axis=0)).all()                     # Hit
+            assert bl[i, 16:21].sum() == bl[i, 21:26].sum() == (d.sum(axis=1) > 0).sum()
+    # monotone in the threshold: eq <= hamming 2 <= levenshtein 2, level by level
+    assert (res[(0, 0)][:, 6:11] <= res[(1, 2)][:, 6:11]).all()
+    assert (res[(1, 2)][:, 6:11] <= res[(2, 2)][:, 6:11]).all()
+    assert res[(0, 0)][:, 6:11].sum() > 0
+    # one whole tile against the oracle (planes generated by numpy, not downloaded)
+    planes, filt, c2, n2, _ = compact_tile(spec, 1, 1102, list(range(L)), centre, nbr)
+    for (mode, k), bl in res.items():
+        valid, dups, ln, _ = oracle.count_tile(planes, filt, c2, lvl_off, n2, mode, k)
+        assert (blocks_to_reference(bl[1], 5) == oracle.tally_tile(valid, dups, ln)).all()
+    tb.free()

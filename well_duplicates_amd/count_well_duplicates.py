@@ -1,0 +1,188 @@
+#!/usr/bin/env python3
+"""count_well_duplicates on an MI355X: same CLI, targets-file format and report as the
+reference's count_well_duplicates.py, with the per-tile gather + compare + tally
+(count_well_duplicates.py:212-265, :63-106) running in libwelldup.so.
+
+Flow per lane (the reference's unit of output, :207-269):
+  read the scanned cycles' planes + filter of every tile (threads: gunzip releases the GIL)
+  -> upload into an HBM-resident TileBatch -> one wd_count_tiles call for the whole batch
+  -> per-tile integer blocks -> report.write_report (text identical to output_writer).
+Unless -q is given the stderr log is reproduced too, including the three lines the
+reference prints per duplicate (:258-262), from the device's hit list.
+
+Differences from the reference, all deliberate:
+  * a lane with valid targets but no duplicate prints 0.00 % instead of dying with
+    ZeroDivisionError (F5); --strict restores the exception;
+  * `-t` with a pattern that matches nothing raises the AssertionError the reference
+    intends (its own message formatting raises NameError first);
+  * extra flags: --device, --tile-batch, --threads, --strict.
+"""
+from __future__ import annotations
+
+import os
+import sys
+from argparse import ArgumentDefaultsHelpFormatter, ArgumentParser
+from concurrent.futures import ThreadPoolExecutor
+
+import numpy as np
+
+from . import bcl as bcl_direct_reader
+from . import report, workload
+from .report import LENGTH, TALLY, output_writer  # noqa: F401  (reference module surface)
+from .scanner import INVALID_TARGET, Scanner, TileBatch, compare_mode
+from .targets import load_targets
+
+__VERSION__ = 0.3        # report format version of the reference this mirrors (:4)
+
+HISEQ_4000 = workload.HISEQ_4000
+HISEQ_X = workload.HISEQ_X
+SEQUENCE = bcl_direct_reader.SEQUENCE
+QUAL_FLAG = bcl_direct_reader.QUAL_FLAG
+
+
+def parse_args(argv=None):
+    """Same options as the reference (count_well_duplicates.py:272-317) plus device knobs."""
+    description = """Assess well duplicates in a run without mapping. Reads within level l of
+    selected reads from the coordinate file are compared with the centre read (edit distance,
+    or Hamming distance with --hamming) on an AMD MI355X."""
+    p = ArgumentParser(description=description, formatter_class=ArgumentDefaultsHelpFormatter)
+    p.add_argument("-f", "--coord_file", dest="coord_file", required=True,
+                   help="The file containing the random sample per tile.")
+    p.add_argument("-e", "--edit_distance", dest="edit_distance", type=int, default=2,
+                   help="max edit distance between two reads to count as duplicate")
+    p.add_argument("-n", "--sample_size", dest="sample_size", type=int, default=2500,
+                   help="number of reads to be tested for well duplicates")
+    p.add_argument("-l", "--level", dest="level", type=int, default=3,
+                   help="levels around central spot to test")
+    p.add_argument("-s", "--stype", dest="stype", required=True,
+                   help="Sequencer model. Can be {} or {} or else the highest tile number in which "
+                        "case the tile/swath configuration will be inferred.".format(HISEQ_4000, HISEQ_X))
+    p.add_argument("-r", "--run", dest="run", required=True,
+                   help="path to base of run, i.e /ifs/seqdata/150715_K00169_0016_BH3FGFBBXX")
+    p.add_argument("-t", "--tile", dest="tile_id", type=str,
+                   help="comma-separated list of specific tiles on a lane to analyse; each item "
+                        "is a regex, so 1... is the top surface only.")
+    p.add_argument("-i", "--lane", dest="lane", type=str,
+                   help="comma-separated list of specific lanes to analyse, 1-8")
+    p.add_argument("-x", "--start", dest="start", type=int, default=50,
+                   help="Starting cycle/base position for the slice of read to be examined")
+    p.add_argument("-y", "--end", dest="end", type=int, default=100,
+                   help="Final cycle/base position for the slice of read to be examined")
+    p.add_argument("--cycles",
+                   help="Cycles/bases to scan as a list of ranges, eg. 10-50,100-120. Overrides -x/-y.")
+    p.add_argument("--hamming", action="store_true",
+                   help="Compare sequences using the Hamming distance rather than the "
+                        "Levenshtein edit distance.")
+    p.add_argument("-S", "--summary-only", action="store_true",
+                   help="Only print the summary per lane, not for every tile")
+    p.add_argument("-q", "--quiet", action="store_true", help="No log output")
+    p.add_argument("--version", action="version", version=str(__VERSION__))
+    p.add_argument("--device", type=int, default=0, help="GPU to run on")
+    p.add_argument("--tile-batch", type=int, default=32,
+                   help="tiles kept resident in HBM and scanned per launch")
+    p.add_argument("--threads", type=int, default=min(16, os.cpu_count() or 1),
+                   help="reader threads (gunzip)")
+    p.add_argument("--strict", action="store_true",
+                   help="reproduce the reference's ZeroDivisionError on a lane without duplicates")
+    return p.parse_args(argv)
+
+
+def _decode(seq_bytes: np.ndarray) -> str:
+    """BCL bytes of one well over the scanned cycles -> the reference's string."""
+    lut = np.frombuffer(b"NACGT", dtype="S1")
+    return lut[np.where(seq_bytes == 0, 0, (seq_bytes & 3) + 1)].tobytes().decode()
+
+
+def scan_lane(sc: Scanner, reader, lane, tiles, cycle_list, mode, k, csr, wells, tile_batch,
+              threads, want_log):
+    """All tiles of one lane -> ({tile: TileCounts}, {tile: [log lines]})."""
+    centre, lvl_off, nbr = csr
+    levels = lvl_off.shape[1] - 1
+    counts, logs = {}, {}
+    pool = ThreadPoolExecutor(max_workers=max(1, threads))
+    for b0 in range(0, len(tiles), tile_batch):
+        chunk = tiles[b0:b0 + tile_batch]
+        handles = [reader.get_tile(lane, t) for t in chunk]
+        n_clusters = handles[0].num_clusters if handles else 0
+        for h in handles:
+            # one targets file, hence one geometry, per flowcell (README.md:14)
+            if h.num_clusters != n_clusters:
+                raise RuntimeError("tiles of one batch differ in cluster count")
+        tb = TileBatch(sc, len(chunk), len(cycle_list), n_clusters)
+        seq_bytes = {}
+        try:
+            for i, h in enumerate(handles):
+                planes = list(pool.map(h.read_plane, cycle_list))
+                filt = h.read_filter()
+                tb.upload_tile(i, planes, filt)
+                if want_log and wells.size:
+                    # keep only the bytes of wells some target touches, for the stderr log
+                    if wells[-1] >= n_clusters or wells[0] < 0:
+                        raise IndexError("Requested cluster %i is out of range.  Highest on this "
+                                         "tile is %i." % (int(wells[-1]), n_clusters - 1))
+                    seq_bytes[i] = np.stack([p[wells] for p in planes], axis=1) if planes else \
+                        np.zeros((wells.size, 0), np.uint8)
+            if want_log:
+                sc.hitlog_enable(max(1024, int(nbr.size) * len(chunk)))
+            blocks, _ = tb.count(mode, k)
+            hits = None
+            if want_log:
+                hits, total = sc.hitlog_fetch(max(1024, int(nbr.size) * len(chunk)))
+                sc.hitlog_enable(0)
+                order = np.lexsort((hits["slot"], hits["target"], hits["tile"]))
+                hits = hits[order]
+        finally:
+            tb.free()
+        for i, t in enumerate(chunk):
+            counts[t] = report.TileCounts.from_block(blocks[i], levels)
+            if want_log:
+                lines = ["Reading tile %s in lane %s" % (t, lane),
+                         "Got %i sequences from %i contiguous cycle ranges." % (
+                             wells.size * want_log, want_log)]
+                sel = hits[hits["tile"] == i]
+                sb = seq_bytes.get(i)
+                for h in sel:
+                    c, w = int(centre[h["target"]]), int(nbr[h["slot"]])
+                    cs = _decode(sb[np.searchsorted(wells, c)])
+                    ws = _decode(sb[np.searchsorted(wells, w)])
+                    lines.append("center seq at {:>07}: {}".format(c, cs))
+                    lines.append("well seq at   {:>07}: {}".format(w, ws))
+                    lines.append("edit distance: {}".format(int(h["dist"])))
+                logs[t] = lines
+    pool.shutdown()
+    return counts, logs
+
+
+def main(argv=None):
+    args = parse_args(argv)
+    log = (lambda msg: None) if args.quiet else (lambda msg: print(str(msg), file=sys.stderr))
+
+    lanes = args.lane.split(",") if args.lane else range(1, 8 + 1)
+    tiles = workload.tiles_for_stype(args.stype)
+    if args.tile_id:
+        tiles = workload.filter_tiles(tiles, args.tile_id, args.stype)
+    cycles = workload.parse_cycles(args.start, args.end, args.cycles)
+    cycle_list = [c for s, e in cycles for c in range(s, e)]
+    mode, k = compare_mode(args.edit_distance, args.hamming)
+
+    targets = load_targets(filename=args.coord_file, levels=args.level + 1, limit=args.sample_size)
+    csr = targets.to_csr(args.level)
+    wells = np.unique(np.asarray(targets.get_all_indices(), dtype=np.int64))
+    reader = bcl_direct_reader.BCLReader(args.run)
+
+    with Scanner(args.device) as sc:
+        sc.set_targets(*csr)
+        for lane in lanes:
+            counts, logs = scan_lane(sc, reader, lane, tiles, cycle_list, mode, k, csr, wells,
+                                     max(1, args.tile_batch), args.threads,
+                                     0 if args.quiet else len(cycles))
+            for t in tiles:
+                for line in logs.get(t, ()):
+                    log(line)
+            report.write_report(lane, len(targets), counts, verbose=not args.summary_only,
+                                strict=args.strict)
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
