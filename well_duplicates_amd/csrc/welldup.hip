@@ -251,10 +251,30 @@ struct LevState {
 // One wave = one target at a time; one lane = one neighbour slot (two slots per lane per
 // pass, 128 slots per pass).  B1 cycles are read unconditionally, then batches of B2 cycles
 // only by lanes that can still become a duplicate.
+//
+// Latency structure (the kernel is bound by dependent HBM round trips, not by bytes):
+//   * the block's target metadata (centre, ring offsets) is staged once into LDS;
+//   * while target t's plane bytes are in flight the wave already issues target t+1's filter
+//     byte and neighbour-index loads (one-target-ahead software pipeline), so the only
+//     dependent HBM trip left per target is the plane gather itself;
+//   * the centre's byte is taken from an idle lane of the second slot (idle lanes shadow the
+//     centre index) instead of a third load per cycle;
+//   * tallies accumulate in registers (lane l = level l) and reach LDS once per wave.
+constexpr int kMaxTpb = 64;
+
+struct TargetRegs {
+    uint32_t c;      // centre index
+    int off0, K;     // first neighbour slot, number of slots
+    uint32_t fb;     // centre's filter byte
+    uint32_t i0, i1; // neighbour indices of slots lane, lane + 64 (centre index when idle)
+};
+
 template <class State, bool STRIDED, int B1, int B2>
 __global__ __launch_bounds__(kBlock) void k_scan(ScanArgs a)
 {
     __shared__ uint32_t s_cnt[kCounters];
+    __shared__ int32_t s_centre[kMaxTpb];
+    __shared__ int32_t s_off[kMaxTpb * (kMaxLevels + 1)];
     const int lane = threadIdx.x & (kWave - 1);
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int levels = a.levels;
@@ -265,9 +285,15 @@ __global__ __launch_bounds__(kBlock) void k_scan(ScanArgs a)
     const int chunks = (a.T + a.tpb - 1) / a.tpb;
     const int tile = blockIdx.x / chunks;
     const int chunk = blockIdx.x - tile * chunks;
+    const int t_first = chunk * a.tpb;
+    const int n_t = min(a.tpb, a.T - t_first);
 
     for (int i = threadIdx.x; i < ncnt; i += kBlock)
         s_cnt[i] = 0;
+    for (int i = threadIdx.x; i < n_t; i += kBlock)
+        s_centre[i] = a.centre[t_first + i];
+    for (int i = threadIdx.x; i < n_t * (levels + 1); i += kBlock)
+        s_off[i] = a.lvl_off[(size_t)t_first * (levels + 1) + i];
     __syncthreads();
 
     const uint8_t *filt = a.filter[tile];
@@ -277,43 +303,70 @@ __global__ __launch_bounds__(kBlock) void k_scan(ScanArgs a)
     auto plane_ptr = [&](int j) -> const uint8_t * {
         return STRIDED ? base0 + (int64_t)j * stride : ptab[j];
     };
+    // metadata + first-pass neighbour indices + filter byte of local target tl
+    auto fetch = [&](int tl) -> TargetRegs {
+        TargetRegs r;
+        r.c = (uint32_t)s_centre[tl];
+        r.off0 = s_off[tl * (levels + 1)];
+        r.K = s_off[tl * (levels + 1) + levels] - r.off0;
+        r.fb = filt[r.c];
+        r.i0 = lane < r.K ? (uint32_t)a.nbr[r.off0 + lane] : r.c;
+        r.i1 = lane + kWave < r.K ? (uint32_t)a.nbr[r.off0 + kWave + lane] : r.c;
+        return r;
+    };
 
-    const int t_end = min(a.T, (chunk + 1) * a.tpb);
-    for (int t = chunk * a.tpb + wave; t < t_end; t += kWaves) {
-        const int32_t *off = a.lvl_off + (size_t)t * (levels + 1);
-        const uint32_t c = (uint32_t)a.centre[t];
-        const int off0 = off[0];
-        const int K = off[levels] - off0;
-        // centre filter gate (count_well_duplicates.py:236-237)
-        const uint32_t fb = __builtin_amdgcn_readfirstlane((uint32_t)filt[c]);
+    // per-wave tallies, lane l = level l
+    uint32_t acc_wells = 0, acc_dups = 0, acc_hit = 0, acc_first = 0, acc_last = 0, acc_valid = 0;
+
+    TargetRegs cur;
+    if (wave < n_t)
+        cur = fetch(wave);
+    for (int tl = wave; tl < n_t; tl += kWaves) {
+        const int t = t_first + tl;
+        const uint32_t c = cur.c;
+        const int off0 = cur.off0;
+        const int K = cur.K;
+        const bool valid = __builtin_amdgcn_readfirstlane(cur.fb) & 1u;   // :236-237
+        const bool have_next = tl + kWaves < n_t;
         uint32_t *opt = a.out_per_target
                             ? a.out_per_target + ((size_t)tile * a.T + t) * levels
                             : nullptr;
-        if (!(fb & 1u)) {
+        TargetRegs nxt = cur;
+        if (!valid) {
+            if (have_next)
+                nxt = fetch(tl + kWaves);
             if (opt && lane < levels)
                 opt[lane] = WD_INVALID_TARGET;
+            cur = nxt;
             continue;
         }
         int my_lo = 0, my_hi = 0;   // lane l < levels: ring l+1 is slots [my_lo, my_hi)
         if (lane < levels) {
-            my_lo = off[lane] - off0;
-            my_hi = off[lane + 1] - off0;
+            my_lo = s_off[tl * (levels + 1) + lane] - off0;
+            my_hi = s_off[tl * (levels + 1) + lane + 1] - off0;
         }
+        bool skip = false;
         if (a.check_empty) {        // count_well_duplicates.py:249
             if (__ballot(lane < levels && my_hi <= my_lo)) {
                 if (lane == 0)
                     atomicOr(a.status, kStatusEmptyLevel);
-                continue;
+                skip = true;
             }
         }
         uint32_t my_d = 0;
+        bool prefetched = false;
 
-        for (int base = 0; base < K; base += 2 * kWave) {
+        for (int base = 0; base < K && !skip; base += 2 * kWave) {
             const int e0 = base + lane, e1 = e0 + kWave;
             const bool a0 = e0 < K, a1 = e1 < K;
-            // idle lanes shadow the centre well: their loads hit the centre's own line
-            const uint32_t i0 = a0 ? (uint32_t)a.nbr[off0 + e0] : c;
-            const uint32_t i1 = a1 ? (uint32_t)a.nbr[off0 + e1] : c;
+            uint32_t i0 = cur.i0, i1 = cur.i1;
+            if (base > 0) {
+                // idle lanes shadow the centre well: their loads hit the centre's own line
+                i0 = a0 ? (uint32_t)a.nbr[off0 + e0] : c;
+                i1 = a1 ? (uint32_t)a.nbr[off0 + e1] : c;
+            }
+            // lane 63 of the second slot is idle (and so reads the centre) unless the pass is full
+            const bool centre_in_lane = base + 2 * kWave > K;
             State s0, s1;
             s0.init(cap);
             s1.init(cap);
@@ -327,14 +380,22 @@ __global__ __launch_bounds__(kBlock) void k_scan(ScanArgs a)
 #pragma unroll
                 for (int q = 0; q < B1; q++) {
                     const uint8_t *p = plane_ptr(min(j + q, L - 1));
-                    cb[q] = p[c];
                     w0[q] = p[i0];
                     w1[q] = p[i1];
+                    if (!centre_in_lane)
+                        cb[q] = p[c];
+                }
+                if (have_next && !prefetched) {     // next target's metadata rides behind
+                    nxt = fetch(tl + kWaves);
+                    prefetched = true;
                 }
 #pragma unroll
                 for (int q = 0; q < B1; q++) {
                     if (j + q < L) {
-                        const uint32_t cc = code_of(cb[q]);
+                        const uint32_t cbyte = centre_in_lane
+                                                   ? (uint32_t)__builtin_amdgcn_readlane((int)w1[q], kWave - 1)
+                                                   : cb[q];
+                        const uint32_t cc = code_of(cbyte);
                         ch = (ch << 3) | cc;
                         s0.push(j + q + 1, ch, cc, code_of(w0[q]), L, cap);
                         s1.push(j + q + 1, ch, cc, code_of(w1[q]), L, cap);
@@ -414,27 +475,35 @@ __global__ __launch_bounds__(kBlock) void k_scan(ScanArgs a)
                 }
             }
         }
+        if (have_next && !prefetched)
+            nxt = fetch(tl + kWaves);
+        cur = nxt;
+        if (skip)
+            continue;
 
         // ---- tally (count_well_duplicates.py:80-95 as histograms; include/welldup.h) ----
         const uint64_t hm = __ballot(lane < levels && my_d > 0);
-        if (lane < levels) {
-            atomicAdd(&s_cnt[1 + lane], (uint32_t)(my_hi - my_lo));
-            if (my_d) {
-                atomicAdd(&s_cnt[1 + levels + lane], my_d);
-                atomicAdd(&s_cnt[1 + 2 * levels + lane], 1u);
-            }
-            if (opt)
-                opt[lane] = my_d;
+        acc_valid += 1;
+        acc_wells += (uint32_t)(my_hi - my_lo);
+        acc_dups += my_d;
+        acc_hit += my_d ? 1u : 0u;
+        if (hm) {
+            acc_first += (lane == __ffsll((long long)hm) - 1) ? 1u : 0u;
+            acc_last += (lane == 63 - __clzll((long long)hm)) ? 1u : 0u;
         }
-        if (lane == 0) {
-            atomicAdd(&s_cnt[0], 1u);
-            if (hm) {
-                atomicAdd(&s_cnt[1 + 3 * levels + (__ffsll((long long)hm) - 1)], 1u);
-                atomicAdd(&s_cnt[1 + 4 * levels + (63 - __clzll((long long)hm))], 1u);
-            }
-        }
+        if (opt && lane < levels)
+            opt[lane] = my_d;
     }
 
+    if (lane < levels) {
+        if (acc_wells) atomicAdd(&s_cnt[1 + lane], acc_wells);
+        if (acc_dups) atomicAdd(&s_cnt[1 + levels + lane], acc_dups);
+        if (acc_hit) atomicAdd(&s_cnt[1 + 2 * levels + lane], acc_hit);
+        if (acc_first) atomicAdd(&s_cnt[1 + 3 * levels + lane], acc_first);
+        if (acc_last) atomicAdd(&s_cnt[1 + 4 * levels + lane], acc_last);
+    }
+    if (lane == 0 && acc_valid)
+        atomicAdd(&s_cnt[0], acc_valid);
     __syncthreads();
     for (int i = threadIdx.x; i < ncnt; i += kBlock) {
         const uint32_t v = s_cnt[i];
@@ -501,9 +570,9 @@ struct wd_ctx {
 
     // options
     int early_exit = 1;
-    int tpb = 8;
+    int tpb = 32;
     int batch_first = 4;
-    int batch_next = 8;
+    int batch_next = 4;
     int profile = 0;
 
     // targets (device)
@@ -759,8 +828,8 @@ int wd_set_option(wd_ctx *ctx, const char *name, int64_t value)
     if (n == "early_exit") {
         ctx->early_exit = value ? 1 : 0;
     } else if (n == "targets_per_block") {
-        if (value < 1 || value > 4096)
-            return fail(ctx, WD_ERR_ARG, "targets_per_block out of range");
+        if (value < 1 || value > kMaxTpb)
+            return fail(ctx, WD_ERR_ARG, "targets_per_block must be 1..64");
         ctx->tpb = (int)value;
     } else if (n == "batch_first") {
         ctx->batch_first = (int)value;
