@@ -14,7 +14,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 REPO = os.path.dirname(HERE)
 SRC = os.path.join(HERE, "csrc", "welldup.hip")
 INCLUDE = os.path.join(REPO, "include")
-LIB_PATH = os.path.join(HERE, "libwelldup.so")
+# WELLDUP_LIB selects another build of the same ABI (kernel A/B experiments)
+LIB_PATH = os.environ.get("WELLDUP_LIB") or os.path.join(HERE, "libwelldup.so")
 
 OK = 0
 ERR_ARG, ERR_INDEX, ERR_EMPTY_LEVEL, ERR_HIP, ERR_NOMEM, ERR_STATE, ERR_UNSUPPORTED, ERR_COMM = \

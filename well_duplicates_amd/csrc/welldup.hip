@@ -143,11 +143,16 @@ struct ScanArgs {
     const int32_t *nbr;
     unsigned long long *out_tile;   // [n_tiles][1 + 5*levels]
     uint32_t *out_per_target;       // nullable [n_tiles][T][levels]
+    const struct ScanRare *rare;    // rarely-touched arguments, read only on the rare paths
+    int T, levels, L, k, tpb, early, check_empty, log_hits;
+};
+
+// Kept out of the kernel-argument registers: only duplicates and malformed targets need them.
+struct ScanRare {
     uint32_t *status;
-    wd_hit *hits;                   // nullable
+    wd_hit *hits;
     unsigned long long *hit_count;
     long long hit_cap;
-    int T, levels, L, k, tpb, early, check_empty;
 };
 
 // Symbol code of a BCL byte: 0 -> 4 ('N'), else byte & 3 (bcl_direct_reader.py:352-361).
@@ -168,6 +173,8 @@ __device__ inline uint64_t range_mask(int lo, int hi)
 
 // ---- per-entry compare state: Hamming (also equality, k = 0) -------------------------
 struct HamState {
+    // register budget hint: 7 waves/SIMD (<= 72 VGPRs) measured best on MI355X (8 spills)
+    static constexpr int kMinWavesPerSimd = 7;
     int mm;
     __device__ void init(int) { mm = 0; }
     // p = 1-based cycle just pushed; cc/wc = centre / well codes of that cycle
@@ -185,6 +192,7 @@ struct HamState {
 // processed H cycles after cycle i arrives; values saturate at cap = k + 1.
 template <int H>
 struct LevState {
+    static constexpr int kMinWavesPerSimd = 1;
     static constexpr int W = 2 * H + 1;
     int r[W];
     uint64_t wh;   // well codes, newest in bits [0,3)
@@ -262,15 +270,8 @@ struct LevState {
 //   * tallies accumulate in registers (lane l = level l) and reach LDS once per wave.
 constexpr int kMaxTpb = 64;
 
-struct TargetRegs {
-    uint32_t c;      // centre index
-    int off0, K;     // first neighbour slot, number of slots
-    uint32_t fb;     // centre's filter byte
-    uint32_t i0, i1; // neighbour indices of slots lane, lane + 64 (centre index when idle)
-};
-
 template <class State, bool STRIDED, int B1, int B2>
-__global__ __launch_bounds__(kBlock) void k_scan(ScanArgs a)
+__global__ __launch_bounds__(kBlock, State::kMinWavesPerSimd) void k_scan(ScanArgs a)
 {
     __shared__ uint32_t s_cnt[kCounters];
     __shared__ int32_t s_centre[kMaxTpb];
@@ -303,41 +304,43 @@ __global__ __launch_bounds__(kBlock) void k_scan(ScanArgs a)
     auto plane_ptr = [&](int j) -> const uint8_t * {
         return STRIDED ? base0 + (int64_t)j * stride : ptab[j];
     };
-    // metadata + first-pass neighbour indices + filter byte of local target tl
-    auto fetch = [&](int tl) -> TargetRegs {
-        TargetRegs r;
-        r.c = (uint32_t)s_centre[tl];
-        r.off0 = s_off[tl * (levels + 1)];
-        r.K = s_off[tl * (levels + 1) + levels] - r.off0;
-        r.fb = filt[r.c];
-        r.i0 = lane < r.K ? (uint32_t)a.nbr[r.off0 + lane] : r.c;
-        r.i1 = lane + kWave < r.K ? (uint32_t)a.nbr[r.off0 + kWave + lane] : r.c;
-        return r;
-    };
 
     // per-wave tallies, lane l = level l
     uint32_t acc_wells = 0, acc_dups = 0, acc_hit = 0, acc_first = 0, acc_last = 0, acc_valid = 0;
 
-    TargetRegs cur;
+    // Registers of the target one step ahead: wave-uniform c / off0 / K, the centre's filter
+    // byte and the first-pass neighbour indices (the centre index in idle lanes).
+    int n_c = 0, n_off0 = 0, n_K = 0;
+    uint32_t n_fb = 0, n_i0 = 0, n_i1 = 0;
+#define WD_FETCH(TL)                                                                      \
+    do {                                                                                  \
+        const int tl_ = (TL);                                                             \
+        n_c = __builtin_amdgcn_readfirstlane(s_centre[tl_]);                              \
+        n_off0 = __builtin_amdgcn_readfirstlane(s_off[tl_ * (levels + 1)]);               \
+        n_K = __builtin_amdgcn_readfirstlane(s_off[tl_ * (levels + 1) + levels]) - n_off0; \
+        n_fb = filt[(uint32_t)n_c];                                                       \
+        n_i0 = lane < n_K ? (uint32_t)a.nbr[n_off0 + lane] : (uint32_t)n_c;               \
+        n_i1 = lane + kWave < n_K ? (uint32_t)a.nbr[n_off0 + kWave + lane] : (uint32_t)n_c; \
+    } while (0)
+
     if (wave < n_t)
-        cur = fetch(wave);
+        WD_FETCH(wave);
     for (int tl = wave; tl < n_t; tl += kWaves) {
         const int t = t_first + tl;
-        const uint32_t c = cur.c;
-        const int off0 = cur.off0;
-        const int K = cur.K;
-        const bool valid = __builtin_amdgcn_readfirstlane(cur.fb) & 1u;   // :236-237
-        const bool have_next = tl + kWaves < n_t;
+        const uint32_t c = (uint32_t)__builtin_amdgcn_readfirstlane(n_c);
+        const int off0 = __builtin_amdgcn_readfirstlane(n_off0);
+        const int K = __builtin_amdgcn_readfirstlane(n_K);
+        const bool valid = __builtin_amdgcn_readfirstlane(n_fb) & 1u;   // :236-237
+        const uint32_t c_i0 = n_i0, c_i1 = n_i1;
+        // the wave's next target (clamped: the last one re-fetches itself, harmlessly)
+        const int tl_next = min(tl + kWaves, n_t - 1);
         uint32_t *opt = a.out_per_target
                             ? a.out_per_target + ((size_t)tile * a.T + t) * levels
                             : nullptr;
-        TargetRegs nxt = cur;
         if (!valid) {
-            if (have_next)
-                nxt = fetch(tl + kWaves);
+            WD_FETCH(tl_next);
             if (opt && lane < levels)
                 opt[lane] = WD_INVALID_TARGET;
-            cur = nxt;
             continue;
         }
         int my_lo = 0, my_hi = 0;   // lane l < levels: ring l+1 is slots [my_lo, my_hi)
@@ -349,7 +352,7 @@ __global__ __launch_bounds__(kBlock) void k_scan(ScanArgs a)
         if (a.check_empty) {        // count_well_duplicates.py:249
             if (__ballot(lane < levels && my_hi <= my_lo)) {
                 if (lane == 0)
-                    atomicOr(a.status, kStatusEmptyLevel);
+                    atomicOr(a.rare->status, kStatusEmptyLevel);
                 skip = true;
             }
         }
@@ -359,7 +362,7 @@ __global__ __launch_bounds__(kBlock) void k_scan(ScanArgs a)
         for (int base = 0; base < K && !skip; base += 2 * kWave) {
             const int e0 = base + lane, e1 = e0 + kWave;
             const bool a0 = e0 < K, a1 = e1 < K;
-            uint32_t i0 = cur.i0, i1 = cur.i1;
+            uint32_t i0 = c_i0, i1 = c_i1;
             if (base > 0) {
                 // idle lanes shadow the centre well: their loads hit the centre's own line
                 i0 = a0 ? (uint32_t)a.nbr[off0 + e0] : c;
@@ -385,8 +388,8 @@ __global__ __launch_bounds__(kBlock) void k_scan(ScanArgs a)
                     if (!centre_in_lane)
                         cb[q] = p[c];
                 }
-                if (have_next && !prefetched) {     // next target's metadata rides behind
-                    nxt = fetch(tl + kWaves);
+                if (!prefetched) {                  // next target's metadata rides behind
+                    WD_FETCH(tl_next);
                     prefetched = true;
                 }
 #pragma unroll
@@ -461,23 +464,23 @@ __global__ __launch_bounds__(kBlock) void k_scan(ScanArgs a)
                     my_d += __popcll(m0 & range_mask(my_lo - base, my_hi - base));
                     my_d += __popcll(m1 & range_mask(my_lo - base - kWave, my_hi - base - kWave));
                 }
-                if (a.hits) {
+                if (a.log_hits) {
+                    const ScanRare r = *a.rare;
                     if (d0) {
-                        unsigned long long h = atomicAdd(a.hit_count, 1ull);
-                        if ((long long)h < a.hit_cap)
-                            a.hits[h] = wd_hit{tile, t, off0 + e0, s0.dist()};
+                        unsigned long long h = atomicAdd(r.hit_count, 1ull);
+                        if ((long long)h < r.hit_cap)
+                            r.hits[h] = wd_hit{tile, t, off0 + e0, s0.dist()};
                     }
                     if (d1) {
-                        unsigned long long h = atomicAdd(a.hit_count, 1ull);
-                        if ((long long)h < a.hit_cap)
-                            a.hits[h] = wd_hit{tile, t, off0 + e1, s1.dist()};
+                        unsigned long long h = atomicAdd(r.hit_count, 1ull);
+                        if ((long long)h < r.hit_cap)
+                            r.hits[h] = wd_hit{tile, t, off0 + e1, s1.dist()};
                     }
                 }
             }
         }
-        if (have_next && !prefetched)
-            nxt = fetch(tl + kWaves);
-        cur = nxt;
+        if (!prefetched)
+            WD_FETCH(tl_next);
         if (skip)
             continue;
 
@@ -504,6 +507,7 @@ __global__ __launch_bounds__(kBlock) void k_scan(ScanArgs a)
     }
     if (lane == 0 && acc_valid)
         atomicAdd(&s_cnt[0], acc_valid);
+#undef WD_FETCH
     __syncthreads();
     for (int i = threadIdx.x; i < ncnt; i += kBlock) {
         const uint32_t v = s_cnt[i];
@@ -589,6 +593,8 @@ struct wd_ctx {
     size_t d_tbl_cap = 0;
     uint32_t *d_status = nullptr;
     uint32_t *h_status = nullptr;            // pinned
+    ScanRare *d_rare = nullptr;
+    ScanRare h_rare = {nullptr, nullptr, nullptr, 0};
 
     // sync-call scratch
     unsigned long long *d_out_tile = nullptr;
@@ -758,6 +764,7 @@ wd_ctx *wd_create(int device_id)
     if (hipSetDevice(device_id) != hipSuccess ||
         hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking) != hipSuccess ||
         hipMalloc((void **)&ctx->d_status, sizeof(uint32_t)) != hipSuccess ||
+        hipMalloc((void **)&ctx->d_rare, sizeof(ScanRare)) != hipSuccess ||
         hipHostMalloc((void **)&ctx->h_status, sizeof(uint32_t), hipHostMallocDefault) != hipSuccess ||
         hipMalloc((void **)&ctx->d_hit_count, sizeof(unsigned long long)) != hipSuccess) {
         g_create_status = WD_ERR_HIP;
@@ -789,6 +796,7 @@ void wd_destroy(wd_ctx *ctx)
     (void)hipFree(ctx->d_nbr);
     (void)hipFree(ctx->d_tbl);
     (void)hipFree(ctx->d_status);
+    (void)hipFree(ctx->d_rare);
     (void)hipHostFree(ctx->h_status);
     (void)hipFree(ctx->d_out_tile);
     (void)hipFree(ctx->d_out_pt);
@@ -1060,10 +1068,17 @@ int wd_scan_async(wd_ctx *ctx, int n_tiles, int L, int mode, int k, const uint8_
     a.nbr = ctx->d_nbr;
     a.out_tile = (unsigned long long *)out_tile_dev;
     a.out_per_target = out_per_target_dev;
-    a.status = ctx->d_status;
-    a.hits = ctx->hit_cap > 0 ? ctx->d_hits : nullptr;
-    a.hit_count = ctx->d_hit_count;
-    a.hit_cap = ctx->hit_cap;
+    {
+        ScanRare r{ctx->d_status, ctx->hit_cap > 0 ? ctx->d_hits : nullptr, ctx->d_hit_count,
+                   (long long)ctx->hit_cap};
+        if (memcmp(&r, &ctx->h_rare, sizeof(r)) != 0) {
+            WD_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            WD_HIP(ctx, hipMemcpy(ctx->d_rare, &r, sizeof(r), hipMemcpyHostToDevice));
+            ctx->h_rare = r;
+        }
+    }
+    a.rare = ctx->d_rare;
+    a.log_hits = ctx->hit_cap > 0 ? 1 : 0;
     a.T = ctx->T;
     a.levels = levels;
     a.L = L;
