@@ -14,6 +14,9 @@ from well_duplicates_amd.scanner import INVALID_TARGET, Scanner, TileBatch
 
 pytestmark = pytest.mark.gpu
 
+DEFAULT_OPTIONS = (("early_exit", 1), ("batch_first", 4), ("batch_next", 4), ("targets_per_block", 32),
+                   ("queue_kernel", 1), ("queue_first", 2))
+
 
 @pytest.fixture(scope="module")
 def sc():
@@ -167,6 +170,15 @@ def test_kernel_variants_agree(sc):
     for mode, k in ((0, 0), (1, 2), (2, 2), (2, 5)):
         base[(mode, k)] = tb.count(mode, k, per_target=True)
     try:
+        # queue kernel (default for equality / Hamming): every first-round depth, tpb
+        for qf in (1, 2, 3, 4):
+            for tpb in (1, 5, 32, 64):
+                sc.set_option("queue_first", qf)
+                sc.set_option("targets_per_block", tpb)
+                for (mode, k), (bl, pt) in base.items():
+                    bl2, pt2 = tb.count(mode, k, per_target=True)
+                    assert (bl2 == bl).all() and (pt2 == pt).all(), ("queue", qf, tpb, mode, k)
+        sc.set_option("queue_kernel", 0)
         for early in (0, 1):
             for b1, b2 in ((2, 4), (3, 4), (4, 4), (4, 8), (8, 8)):
                 for tpb in (1, 4, 7, 64):
@@ -179,6 +191,7 @@ def test_kernel_variants_agree(sc):
                         assert (bl2 == bl).all() and (pt2 == pt).all(), (early, b1, b2, tpb, mode, k)
         # pointer-table layout: planes in scrambled order with odd alignments
         sc.set_option("early_exit", 1)
+        sc.set_option("queue_kernel", 1)
         n = spec.n_clusters
         slab = sc.malloc(3 * L * (n + 13) + 64)
         ptrs = [[0] * L for _ in range(3)]
@@ -192,9 +205,45 @@ def test_kernel_variants_agree(sc):
             assert (bl2 == bl).all() and (pt2 == pt).all()
         sc.free(slab)
     finally:
-        for name, v in (("early_exit", 1), ("batch_first", 4), ("batch_next", 8), ("targets_per_block", 8)):
+        for name, v in DEFAULT_OPTIONS:
             sc.set_option(name, v)
     tb.free()
+
+
+@pytest.mark.parametrize("kind", ["all_nocall", "all_copies"])
+def test_low_diversity_stress(sc, kind):
+    """Worst case for the early exit: (nearly) every neighbour equals its centre, so nothing
+    dies early, the survivor queues overflow and drain constantly, and targets with up to
+    4 passes (and > 508 slots: fallback kernel) occur.  Still bit-exact."""
+    rng = np.random.default_rng(11)
+    if kind == "all_nocall":
+        spec = synth.SynthSpec(seed=3, n_clusters=9001, row=97, nocall_per_64k=65536)
+    else:
+        spec = synth.SynthSpec(seed=3, n_clusters=9001, row=1, plant_per_64k=60000, nocall_per_64k=500)
+    L = 23
+    for ring, levels, T in ((60, 5, 150), (126, 4, 80), (200, 3, 40)):
+        centre, lvl_off, nbr = _random_case(rng, spec.n_clusters, T, levels, ring=ring)
+        sc.set_targets(centre, lvl_off, nbr)
+        tb = TileBatch(sc, 2, L, spec.n_clusters)
+        tb.fill_synthetic(spec, [(1, 1101), (2, 1102)], list(range(L)))
+        for mode, k in ((0, 0), (1, 1), (1, 3), (2, 2)):
+            res = {}
+            for q in (0, 1):
+                sc.set_option("queue_kernel", q)
+                res[q] = tb.count(mode, k, per_target=True)
+            sc.set_option("queue_kernel", 1)
+            assert (res[0][0] == res[1][0]).all() and (res[0][1] == res[1][1]).all()
+            for i, (lane, tile) in enumerate([(1, 1101), (2, 1102)]):
+                planes, filt, c2, n2, _ = compact_tile(spec, lane, tile, list(range(L)), centre, nbr)
+                valid, dups, lens, _ = oracle.count_tile(planes, filt, c2, lvl_off, n2, mode, k)
+                want = np.where(valid[:, None] == 1, dups, -1)
+                got = res[1][1][i].astype(np.int64)
+                got[got == INVALID_TARGET] = -1
+                assert (got == want).all(), (kind, ring, mode, k)
+                assert (blocks_to_reference(res[1][0][i], levels) == oracle.tally_tile(valid, dups, lens)).all()
+            if kind == "all_nocall" and mode == 0:
+                assert res[1][0][:, 1 + levels:1 + 2 * levels].sum() == res[1][0][:, 1:1 + levels].sum()  # all dups
+        tb.free()
 
 
 def test_errors_and_edges(sc):

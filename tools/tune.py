@@ -15,7 +15,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from well_duplicates_amd import synth, workload                     # noqa: E402
 from well_duplicates_amd.scanner import Scanner, TileBatch         # noqa: E402
 
-KEYS = {"tpb": "targets_per_block", "b1": "batch_first", "b2": "batch_next", "early": "early_exit"}
+KEYS = {"tpb": "targets_per_block", "b1": "batch_first", "b2": "batch_next", "early": "early_exit",
+        "q": "queue_kernel", "qf": "queue_first"}
 
 
 def main():

@@ -155,6 +155,13 @@ struct ScanRare {
     long long hit_cap;
 };
 
+// Plane / filter pointers reach the kernels through pointer tables in memory, so the compiler
+// only knows them as generic ("flat") addresses: flat loads need a VGPR address pair each and
+// force vmcnt(0)+lgkmcnt(0) waits.  They are device-global by contract (include/welldup.h), so
+// say so: global_load_ubyte with a scalar base, a 32-bit lane offset and counted vmcnt.
+using gbytes = const __attribute__((address_space(1))) uint8_t *;
+__device__ inline gbytes as_global(const uint8_t *p) { return (gbytes)p; }
+
 // Symbol code of a BCL byte: 0 -> 4 ('N'), else byte & 3 (bcl_direct_reader.py:352-361).
 __device__ inline uint32_t code_of(uint32_t b)
 {
@@ -297,12 +304,12 @@ __global__ __launch_bounds__(kBlock, State::kMinWavesPerSimd) void k_scan(ScanAr
         s_off[i] = a.lvl_off[(size_t)t_first * (levels + 1) + i];
     __syncthreads();
 
-    const uint8_t *filt = a.filter[tile];
+    gbytes filt = as_global(a.filter[tile]);
     const uint8_t *const *ptab = STRIDED ? nullptr : a.planes + (size_t)tile * L;
-    const uint8_t *base0 = STRIDED ? a.planes[tile] : nullptr;
+    gbytes base0 = STRIDED ? as_global(a.planes[tile]) : nullptr;
     const int64_t stride = a.stride;
-    auto plane_ptr = [&](int j) -> const uint8_t * {
-        return STRIDED ? base0 + (int64_t)j * stride : ptab[j];
+    auto plane_ptr = [&](int j) -> gbytes {
+        return STRIDED ? base0 + (int64_t)j * stride : as_global(ptab[j]);
     };
 
     // per-wave tallies, lane l = level l
@@ -382,7 +389,7 @@ __global__ __launch_bounds__(kBlock, State::kMinWavesPerSimd) void k_scan(ScanAr
                 uint32_t cb[B1], w0[B1], w1[B1];
 #pragma unroll
                 for (int q = 0; q < B1; q++) {
-                    const uint8_t *p = plane_ptr(min(j + q, L - 1));
+                    gbytes p = plane_ptr(min(j + q, L - 1));
                     w0[q] = p[i0];
                     w1[q] = p[i1];
                     if (!centre_in_lane)
@@ -413,7 +420,7 @@ __global__ __launch_bounds__(kBlock, State::kMinWavesPerSimd) void k_scan(ScanAr
             // ---- later batches: only lanes that can still become a duplicate ----
             while (j < L && __ballot(l0 || l1)) {
                 uint32_t cb[B2], w0[B2], w1[B2];
-                const uint8_t *pp[B2];
+                gbytes pp[B2];
 #pragma unroll
                 for (int q = 0; q < B2; q++) {
                     pp[q] = plane_ptr(min(j + q, L - 1));
@@ -517,6 +524,348 @@ __global__ __launch_bounds__(kBlock, State::kMinWavesPerSimd) void k_scan(ScanAr
 }
 
 // -------------------------------------------------------------------------------------
+// Queue kernel (Hamming family with early exit): the default for equality / Hamming <= k
+// -------------------------------------------------------------------------------------
+// k_scan above pays one dependent HBM round trip per target per round, so reading fewer cycles
+// in the first round (less traffic) only adds rounds (more latency).  This kernel makes the
+// round, not the target, the unit of latency:
+//   phase 0  the block stages its targets' metadata in LDS, reads all their filter bytes in
+//            one go and builds the list of (valid target, pass) work items;
+//   phase 1  each wave streams over its items with a 4-stage software pipeline (neighbour
+//            indices two items ahead, plane bytes one item ahead, all loads unconditional so
+//            the compiler's counted vmcnt keeps two gathers in flight).  Only B1 cycles are
+//            read; neighbours still within k mismatches ("survivors", ~1/4^B1 of them) are
+//            compacted into a small per-wave LDS queue {well index, target, slot, mismatches};
+//   phase 2  the wave drains its queue in rounds of 2, 4, 8, 8, ... further cycles, one lane
+//            per survivor (dense), re-compacting after each round; whoever survives all L
+//            cycles is a duplicate and bumps its target's per-level counter in LDS;
+//   phase 3  per-target tallies -> block histogram (LDS atomics) -> one global atomic each.
+// A pass holds 127 slots: lane 63 of the second slot always shadows the centre well, so the
+// centre's byte comes out of the same load as the neighbours'.
+constexpr int kPass = 127;
+constexpr int kQCap = 128;          // >= kPass: after a drain one pass always fits
+constexpr int kMaxPasses = 4;       // host falls back to k_scan for targets with more slots
+
+__host__ __device__ inline int scan_q_lds_dwords(int levels, int tpb)
+{
+    int n = (1 + 5 * levels) + tpb + tpb * (levels + 1) + tpb * levels + tpb + kMaxPasses * tpb + 4;
+    n = (n + 1) & ~1;               // queue entries are 8-byte pairs
+    return n + kWaves * 2 * kQCap * 2;
+}
+
+template <bool STRIDED, int B1>
+__global__ __launch_bounds__(kBlock, 6) void k_scan_q(ScanArgs a)
+{
+    extern __shared__ uint32_t smem[];
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int levels = a.levels;
+    const int L = a.L;
+    const int k = a.k;
+    const int tpb = a.tpb;
+    const int ncnt = 1 + 5 * levels;
+    const int chunks = (a.T + tpb - 1) / tpb;
+    const int tile = blockIdx.x / chunks;
+    const int chunk = blockIdx.x - tile * chunks;
+    const int t_first = chunk * tpb;
+    const int n_t = min(tpb, a.T - t_first);
+
+    uint32_t *s_cnt = smem;
+    int32_t *s_centre = (int32_t *)(s_cnt + ncnt);
+    int32_t *s_off = s_centre + tpb;
+    uint32_t *s_d = (uint32_t *)(s_off + tpb * (levels + 1));
+    uint32_t *s_valid = s_d + tpb * levels;
+    uint32_t *s_items = s_valid + tpb;
+    uint32_t *s_misc = s_items + kMaxPasses * tpb;
+    const int q_base = (int)((((s_misc + 4) - smem) + 1) & ~1);
+    uint2 *q_a = (uint2 *)(smem + q_base) + wave * 2 * kQCap;
+    uint2 *q_b = q_a + kQCap;
+
+    gbytes filt = as_global(a.filter[tile]);
+    const uint8_t *const *ptab = STRIDED ? nullptr : a.planes + (size_t)tile * L;
+    gbytes base0 = STRIDED ? as_global(a.planes[tile]) : nullptr;
+    const int64_t stride = a.stride;
+    auto plane_ptr = [&](int j) -> gbytes {
+        return STRIDED ? base0 + (int64_t)j * stride : as_global(ptab[j]);
+    };
+
+    // ---------------- phase 0: metadata, filter bytes, work items ----------------
+    for (int i = threadIdx.x; i < ncnt; i += kBlock)
+        s_cnt[i] = 0;
+    for (int i = threadIdx.x; i < n_t * levels; i += kBlock)
+        s_d[i] = 0;
+    for (int i = threadIdx.x; i < n_t; i += kBlock)
+        s_centre[i] = a.centre[t_first + i];
+    for (int i = threadIdx.x; i < n_t * (levels + 1); i += kBlock)
+        s_off[i] = a.lvl_off[(size_t)t_first * (levels + 1) + i];
+    __syncthreads();
+    if (wave == 0) {
+        const bool in = lane < n_t;
+        const int32_t *o = s_off + (in ? lane : 0) * (levels + 1);
+        const uint32_t c = in ? (uint32_t)s_centre[lane] : 0u;
+        const uint32_t fb = in ? (uint32_t)filt[c] : 0u;
+        bool valid = in && (fb & 1u);                          // :236-237
+        if (a.check_empty && valid) {                           // :249
+            bool empty = false;
+            for (int l = 0; l < levels; l++)
+                empty = empty || (o[l + 1] <= o[l]);
+            if (empty) {
+                atomicOr(a.rare->status, kStatusEmptyLevel);
+                valid = false;
+            }
+        }
+        const int K = in ? o[levels] - o[0] : 0;
+        const int np = valid ? (K + kPass - 1) / kPass : 0;
+        int incl = np;
+#pragma unroll
+        for (int d = 1; d < kWave; d <<= 1) {
+            const int v = __shfl_up(incl, d);
+            if (lane >= d)
+                incl += v;
+        }
+        if (in)
+            s_valid[lane] = valid ? 1u : 0u;
+        for (int p = 0; p < np; p++)
+            s_items[incl - np + p] = ((uint32_t)lane << 8) | (uint32_t)p;
+        if (lane == kWave - 1)
+            s_misc[0] = (uint32_t)incl;
+    }
+    __syncthreads();
+
+    // a duplicate found: bump its target's per-level counter (and the optional hit log)
+    auto record_dup = [&](int tl, int e, int dist) {
+        const int32_t *o = s_off + tl * (levels + 1);
+        const int rel0 = o[0];
+        int lev = 0;
+        for (int l = 1; l < levels; l++)
+            lev += (e >= o[l] - rel0) ? 1 : 0;
+        atomicAdd(&s_d[tl * levels + lev], 1u);
+        if (a.log_hits) {
+            const ScanRare r = *a.rare;
+            unsigned long long h = atomicAdd(r.hit_count, 1ull);
+            if ((long long)h < r.hit_cap)
+                r.hits[h] = wd_hit{tile, t_first + tl, rel0 + e, dist};
+        }
+    };
+
+    // ---------------- phase 2 (defined first: phase 1 calls it when the queue is full) ------
+    int qn = 0;
+    auto drain = [&]() {
+        // queue pushes by other lanes of this wave must be visible before the reads below
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        int j = min(B1, L);
+        int nb = 2;
+        uint2 *qa = q_a, *qb = q_b;
+        int n = qn;
+        while (n > 0 && j < L) {
+            const bool last = j + nb >= L;
+            int n2 = 0;
+            for (int p0 = 0; p0 < n; p0 += kWave) {
+                const bool have = p0 + lane < n;
+                uint2 ent = make_uint2(0u, 0u);
+                if (have)
+                    ent = qa[p0 + lane];
+                const uint32_t idx = ent.x;
+                const int tl = (int)(ent.y >> 24);
+                const int e = (int)(ent.y & 0xFFFFu);
+                int mm = (int)((ent.y >> 16) & 0xFFu);
+                if (have) {
+                    const uint32_t c = (uint32_t)s_centre[tl];
+                    uint32_t w[8], cb[8];
+#pragma unroll
+                    for (int q = 0; q < 8; q++) {
+                        if (q < nb) {
+                            gbytes p = plane_ptr(min(j + q, L - 1));
+                            w[q] = p[idx];
+                            cb[q] = p[c];
+                        }
+                    }
+#pragma unroll
+                    for (int q = 0; q < 8; q++) {
+                        if (q < nb && j + q < L)
+                            mm += code_of(w[q]) != code_of(cb[q]) ? 1 : 0;
+                    }
+                }
+                const bool alive = have && mm <= k;
+                if (last) {
+                    if (alive)
+                        record_dup(tl, e, mm);
+                } else {
+                    const uint64_t m = __ballot(alive);
+                    if (alive) {
+                        const int pos = n2 + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32),
+                                                 __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+                        qb[pos] = make_uint2(idx, (ent.y & 0xFF00FFFFu) | ((uint32_t)min(mm, 255) << 16));
+                    }
+                    n2 += __popcll(m);
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            uint2 *t = qa; qa = qb; qb = t;
+            n = last ? 0 : n2;
+            j += nb;
+            nb = min(8, nb * 2);
+        }
+        qn = 0;
+    };
+
+    // ---------------- phase 1: pipelined first round over this wave's items -----------------
+    const int nitems = (int)s_misc[0];
+    const int n_my = nitems > wave ? (nitems - wave + kWaves - 1) / kWaves : 0;
+    if (n_my > 0) {
+        // plane pointers of the first round (clamped: cycles >= L are masked out below)
+        gbytes pp[B1];
+#pragma unroll
+        for (int q = 0; q < B1; q++)
+            pp[q] = plane_ptr(min(q, max(L - 1, 0)));
+
+        // item registers by age: 0 = indices being loaded ... 3 = being consumed
+        uint32_t it0 = 0, it1 = 0, it2 = 0, it3 = 0;
+        uint32_t i0_0 = 0, i1_0 = 0, i0_1 = 0, i1_1 = 0, i0_2 = 0, i1_2 = 0, i0_3 = 0, i1_3 = 0;
+        uint32_t w0_2[B1], w1_2[B1], w0_3[B1], w1_3[B1];
+#pragma unroll
+        for (int q = 0; q < B1; q++)
+            w0_2[q] = w1_2[q] = w0_3[q] = w1_3[q] = 0;
+
+        for (int s = 0; s < n_my + 3; s++) {
+            // rotate ages
+            it3 = it2; i0_3 = i0_2; i1_3 = i1_2;
+#pragma unroll
+            for (int q = 0; q < B1; q++) {
+                w0_3[q] = w0_2[q];
+                w1_3[q] = w1_2[q];
+            }
+            it2 = it1; i0_2 = i0_1; i1_2 = i1_1;
+            it1 = it0; i0_1 = i0_0; i1_1 = i1_0;
+
+            // stage B: plane bytes of item s-2 (its indices were requested two steps ago)
+            if (L > 0) {
+#pragma unroll
+                for (int q = 0; q < B1; q++) {
+                    w0_2[q] = pp[q][i0_2];
+                    w1_2[q] = pp[q][i1_2];
+                }
+            }
+            // stage A: neighbour indices of item s (clamped to the wave's last item)
+            {
+                it0 = s_items[wave + kWaves * min(s, n_my - 1)];
+                const int tl = (int)(it0 >> 8);
+                const int base = (int)(it0 & 0xFFu) * kPass;
+                const uint32_t c = (uint32_t)__builtin_amdgcn_readfirstlane(s_centre[tl]);
+                const int off0 = __builtin_amdgcn_readfirstlane(s_off[tl * (levels + 1)]);
+                const int K = __builtin_amdgcn_readfirstlane(s_off[tl * (levels + 1) + levels]) - off0;
+                const int e0 = base + lane, e1 = e0 + kWave;
+                // idle lanes (and always lane 63 of the second slot) shadow the centre well
+                // (loads are unconditional - clamped slot, then select - so that the number of
+                // loads per step is static and the compiler can keep counted vmcnt waits)
+                const uint32_t r0 = (uint32_t)a.nbr[off0 + min(e0, K - 1)];
+                const uint32_t r1 = (uint32_t)a.nbr[off0 + min(e1, K - 1)];
+                i0_0 = e0 < K ? r0 : c;
+                i1_0 = (lane < kWave - 1 && e1 < K) ? r1 : c;
+            }
+            // stage C: consume item s-3
+            if (s >= 3) {
+                const int tl = (int)(it3 >> 8);
+                const int base = (int)(it3 & 0xFFu) * kPass;
+                const int off0 = __builtin_amdgcn_readfirstlane(s_off[tl * (levels + 1)]);
+                const int K = __builtin_amdgcn_readfirstlane(s_off[tl * (levels + 1) + levels]) - off0;
+                const int e0 = base + lane, e1 = e0 + kWave;
+                const bool a0 = e0 < K, a1 = lane < kWave - 1 && e1 < K;
+                int mm0 = 0, mm1 = 0;
+#pragma unroll
+                for (int q = 0; q < B1; q++) {
+                    if (q < L) {
+                        const uint32_t cc = code_of((uint32_t)__builtin_amdgcn_readlane((int)w1_3[q], kWave - 1));
+                        mm0 += code_of(w0_3[q]) != cc ? 1 : 0;
+                        mm1 += code_of(w1_3[q]) != cc ? 1 : 0;
+                    }
+                }
+                const bool al0 = a0 && mm0 <= k, al1 = a1 && mm1 <= k;
+                const uint64_t m0 = __ballot(al0), m1 = __ballot(al1);
+                if (m0 | m1) {
+                    if (B1 >= L) {
+                        if (al0)
+                            record_dup(tl, e0, mm0);
+                        if (al1)
+                            record_dup(tl, e1, mm1);
+                    } else {
+                        const int n0 = __popcll(m0), n1 = __popcll(m1);
+                        if (qn + n0 + n1 > kQCap)
+                            drain();
+                        if (al0) {
+                            const int pos = qn + __builtin_amdgcn_mbcnt_hi((uint32_t)(m0 >> 32),
+                                                     __builtin_amdgcn_mbcnt_lo((uint32_t)m0, 0u));
+                            q_a[pos] = make_uint2(i0_3, ((uint32_t)tl << 24) | ((uint32_t)min(mm0, 255) << 16) | (uint32_t)e0);
+                        }
+                        if (al1) {
+                            const int pos = qn + n0 + __builtin_amdgcn_mbcnt_hi((uint32_t)(m1 >> 32),
+                                                          __builtin_amdgcn_mbcnt_lo((uint32_t)m1, 0u));
+                            q_a[pos] = make_uint2(i1_3, ((uint32_t)tl << 24) | ((uint32_t)min(mm1, 255) << 16) | (uint32_t)e1);
+                        }
+                        qn += n0 + n1;
+                    }
+                }
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (qn > 0)
+            drain();
+    }
+    __syncthreads();
+
+    // ---------------- phase 3: tallies (count_well_duplicates.py:80-95 as histograms) -------
+    uint32_t acc_wells = 0, acc_dups = 0, acc_hit = 0, acc_first = 0, acc_last = 0, acc_valid = 0;
+    for (int tl = wave; tl < n_t; tl += kWaves) {
+        const bool valid = __builtin_amdgcn_readfirstlane(s_valid[tl]) != 0;
+        uint32_t *opt = a.out_per_target
+                            ? a.out_per_target + ((size_t)tile * a.T + t_first + tl) * levels
+                            : nullptr;
+        if (!valid) {
+            if (opt && lane < levels)
+                opt[lane] = WD_INVALID_TARGET;
+            continue;
+        }
+        uint32_t my_d = 0, my_w = 0;
+        if (lane < levels) {
+            my_d = s_d[tl * levels + lane];
+            my_w = (uint32_t)(s_off[tl * (levels + 1) + lane + 1] - s_off[tl * (levels + 1) + lane]);
+        }
+        const uint64_t hm = __ballot(lane < levels && my_d > 0);
+        acc_valid += 1;
+        acc_wells += my_w;
+        acc_dups += my_d;
+        acc_hit += my_d ? 1u : 0u;
+        if (hm) {
+            acc_first += (lane == __ffsll((long long)hm) - 1) ? 1u : 0u;
+            acc_last += (lane == 63 - __clzll((long long)hm)) ? 1u : 0u;
+        }
+        if (opt && lane < levels)
+            opt[lane] = my_d;
+    }
+    if (lane < levels) {
+        if (acc_wells) atomicAdd(&s_cnt[1 + lane], acc_wells);
+        if (acc_dups) atomicAdd(&s_cnt[1 + levels + lane], acc_dups);
+        if (acc_hit) atomicAdd(&s_cnt[1 + 2 * levels + lane], acc_hit);
+        if (acc_first) atomicAdd(&s_cnt[1 + 3 * levels + lane], acc_first);
+        if (acc_last) atomicAdd(&s_cnt[1 + 4 * levels + lane], acc_last);
+    }
+    if (lane == 0 && acc_valid)
+        atomicAdd(&s_cnt[0], acc_valid);
+    __syncthreads();
+    for (int i = threadIdx.x; i < ncnt; i += kBlock) {
+        const uint32_t v = s_cnt[i];
+        if (v)
+            atomicAdd(&a.out_tile[(size_t)tile * ncnt + i], (unsigned long long)v);
+    }
+}
+
+// -------------------------------------------------------------------------------------
 // RCCL, bound at run time
 // -------------------------------------------------------------------------------------
 struct Id128 { char b[WD_UNIQUE_ID_BYTES]; };   // ncclUniqueId, passed by value
@@ -577,6 +926,8 @@ struct wd_ctx {
     int tpb = 32;
     int batch_first = 4;
     int batch_next = 4;
+    int queue_kernel = 1;      // equality / Hamming with early exit: use k_scan_q
+    int queue_first = 2;       // cycles of its first round
     int profile = 0;
 
     // targets (device)
@@ -584,6 +935,7 @@ struct wd_ctx {
     int64_t P = 0;
     int32_t *d_centre = nullptr, *d_lvl_off = nullptr, *d_nbr = nullptr;
     int64_t idx_min = 0, idx_max = -1;
+    int64_t k_max = 0;         // most neighbour slots of any target
     bool has_targets = false;
     bool has_empty_level = false;
 
@@ -703,6 +1055,19 @@ void launch_lev(wd_ctx *ctx, const ScanArgs &a, dim3 grid, bool strided)
     else
         hipLaunchKernelGGL((k_scan<LevState<H>, false, kLevB1, kLevB2>), grid, dim3(kBlock), 0,
                            ctx->stream, a);
+}
+
+template <bool STRIDED>
+int launch_queue(wd_ctx *ctx, const ScanArgs &a, dim3 grid)
+{
+    const size_t lds = (size_t)scan_q_lds_dwords(a.levels, a.tpb) * sizeof(uint32_t);
+    switch (ctx->queue_first) {
+    case 1: hipLaunchKernelGGL((k_scan_q<STRIDED, 1>), grid, dim3(kBlock), lds, ctx->stream, a); break;
+    case 2: hipLaunchKernelGGL((k_scan_q<STRIDED, 2>), grid, dim3(kBlock), lds, ctx->stream, a); break;
+    case 3: hipLaunchKernelGGL((k_scan_q<STRIDED, 3>), grid, dim3(kBlock), lds, ctx->stream, a); break;
+    default: hipLaunchKernelGGL((k_scan_q<STRIDED, 4>), grid, dim3(kBlock), lds, ctx->stream, a); break;
+    }
+    return 0;
 }
 
 bool valid_batches(int b1, int b2)
@@ -845,6 +1210,12 @@ int wd_set_option(wd_ctx *ctx, const char *name, int64_t value)
         ctx->batch_next = (int)value;
     } else if (n == "profile") {
         ctx->profile = value ? 1 : 0;
+    } else if (n == "queue_kernel") {
+        ctx->queue_kernel = value ? 1 : 0;
+    } else if (n == "queue_first") {
+        if (value < 1 || value > 4)
+            return fail(ctx, WD_ERR_ARG, "queue_first must be 1..4");
+        ctx->queue_first = (int)value;
     } else {
         return fail(ctx, WD_ERR_ARG, "unknown option " + n);
     }
@@ -861,6 +1232,8 @@ int wd_get_option(wd_ctx *ctx, const char *name, int64_t *value)
     else if (n == "batch_first") *value = ctx->batch_first;
     else if (n == "batch_next") *value = ctx->batch_next;
     else if (n == "profile") *value = ctx->profile;
+    else if (n == "queue_kernel") *value = ctx->queue_kernel;
+    else if (n == "queue_first") *value = ctx->queue_first;
     else return fail(ctx, WD_ERR_ARG, "unknown option " + n);
     return WD_OK;
 }
@@ -977,6 +1350,9 @@ int wd_set_targets(wd_ctx *ctx, int T, int levels, const int32_t *centre, const 
     ctx->idx_min = T ? lo : 0;
     ctx->idx_max = T ? hi : -1;
     ctx->has_empty_level = empty;
+    ctx->k_max = 0;
+    for (int t = 0; t < T; t++)
+        ctx->k_max = std::max<int64_t>(ctx->k_max, (int64_t)lvl_off[(size_t)t * row + levels] - lvl_off[(size_t)t * row]);
     ctx->has_targets = true;
     return WD_OK;
 }
@@ -1106,7 +1482,14 @@ int wd_scan_async(wd_ctx *ctx, int n_tiles, int L, int mode, int k, const uint8_
         }
         WD_HIP(ctx, hipEventRecord(ev.first, ctx->stream));
     }
-    if (!lev) {
+    const bool use_queue = !lev && ctx->queue_kernel && ctx->early_exit && kk <= 254 &&
+                           ctx->k_max <= (int64_t)kMaxPasses * kPass;
+    if (use_queue) {
+        if (strided)
+            launch_queue<true>(ctx, a, grid);
+        else
+            launch_queue<false>(ctx, a, grid);
+    } else if (!lev) {
         if (strided)
             launch_ham<true>(ctx, a, grid);
         else
