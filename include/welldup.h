@@ -70,8 +70,9 @@ void wd_destroy(wd_ctx *ctx);
 int wd_set_stream(wd_ctx *ctx, void *hip_stream);
 int wd_synchronize(wd_ctx *ctx);
 
-/* Tunables, by name: "early_exit" (1), "targets_per_block" (8), "batch_first" (4),
- * "batch_next" (8), "profile" (0).  Unknown names return WD_ERR_ARG. */
+/* Tunables, by name (default): "early_exit" (1), "targets_per_block" (64), "queue_kernel" (1),
+ * "queue_first" (0 = from k), "batch_first" (4), "batch_next" (4), "profile" (0).
+ * Unknown names return WD_ERR_ARG. */
 int wd_set_option(wd_ctx *ctx, const char *name, int64_t value);
 int wd_get_option(wd_ctx *ctx, const char *name, int64_t *value);
 

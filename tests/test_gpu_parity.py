@@ -15,7 +15,7 @@ from well_duplicates_amd.scanner import INVALID_TARGET, Scanner, TileBatch
 pytestmark = pytest.mark.gpu
 
 DEFAULT_OPTIONS = (("early_exit", 1), ("batch_first", 4), ("batch_next", 4), ("targets_per_block", 32),
-                   ("queue_kernel", 1), ("queue_first", 2))
+                   ("queue_kernel", 1), ("queue_first", 0))
 
 
 @pytest.fixture(scope="module")
@@ -171,8 +171,8 @@ def test_kernel_variants_agree(sc):
         base[(mode, k)] = tb.count(mode, k, per_target=True)
     try:
         # queue kernel (default for equality / Hamming): every first-round depth, tpb
-        for qf in (1, 2, 3, 4):
-            for tpb in (1, 5, 32, 64):
+        for qf in (0, 1, 2, 3, 4, 6, 8):
+            for tpb in (1, 5, 64):
                 sc.set_option("queue_first", qf)
                 sc.set_option("targets_per_block", tpb)
                 for (mode, k), (bl, pt) in base.items():

@@ -543,7 +543,7 @@ __global__ __launch_bounds__(kBlock, State::kMinWavesPerSimd) void k_scan(ScanAr
 // A pass holds 127 slots: lane 63 of the second slot always shadows the centre well, so the
 // centre's byte comes out of the same load as the neighbours'.
 constexpr int kPass = 127;
-constexpr int kQCap = 128;          // >= kPass: after a drain one pass always fits
+constexpr int kQCap = 256;          // >= kPass: after a drain one pass always fits
 constexpr int kMaxPasses = 4;       // host falls back to k_scan for targets with more slots
 
 __host__ __device__ inline int scan_q_lds_dwords(int levels, int tpb)
@@ -923,11 +923,11 @@ struct wd_ctx {
 
     // options
     int early_exit = 1;
-    int tpb = 32;
+    int tpb = 64;
     int batch_first = 4;
     int batch_next = 4;
     int queue_kernel = 1;      // equality / Hamming with early exit: use k_scan_q
-    int queue_first = 2;       // cycles of its first round
+    int queue_first = 0;       // cycles of its first round; 0 = choose from k
     int profile = 0;
 
     // targets (device)
@@ -1061,11 +1061,18 @@ template <bool STRIDED>
 int launch_queue(wd_ctx *ctx, const ScanArgs &a, dim3 grid)
 {
     const size_t lds = (size_t)scan_q_lds_dwords(a.levels, a.tpb) * sizeof(uint32_t);
-    switch (ctx->queue_first) {
+    // A random neighbour survives r cycles with <= k mismatches with probability
+    // sum_{i<=k} C(r,i) 0.75^i 0.25^(r-i); the first round should leave a few percent alive.
+    int first = ctx->queue_first;
+    if (first == 0)
+        first = a.k <= 0 ? 2 : (a.k <= 2 ? 4 : (a.k == 3 ? 6 : 8));   // measured on MI355X
+    switch (first) {
     case 1: hipLaunchKernelGGL((k_scan_q<STRIDED, 1>), grid, dim3(kBlock), lds, ctx->stream, a); break;
     case 2: hipLaunchKernelGGL((k_scan_q<STRIDED, 2>), grid, dim3(kBlock), lds, ctx->stream, a); break;
     case 3: hipLaunchKernelGGL((k_scan_q<STRIDED, 3>), grid, dim3(kBlock), lds, ctx->stream, a); break;
-    default: hipLaunchKernelGGL((k_scan_q<STRIDED, 4>), grid, dim3(kBlock), lds, ctx->stream, a); break;
+    case 4: hipLaunchKernelGGL((k_scan_q<STRIDED, 4>), grid, dim3(kBlock), lds, ctx->stream, a); break;
+    case 6: hipLaunchKernelGGL((k_scan_q<STRIDED, 6>), grid, dim3(kBlock), lds, ctx->stream, a); break;
+    default: hipLaunchKernelGGL((k_scan_q<STRIDED, 8>), grid, dim3(kBlock), lds, ctx->stream, a); break;
     }
     return 0;
 }
@@ -1213,8 +1220,8 @@ int wd_set_option(wd_ctx *ctx, const char *name, int64_t value)
     } else if (n == "queue_kernel") {
         ctx->queue_kernel = value ? 1 : 0;
     } else if (n == "queue_first") {
-        if (value < 1 || value > 4)
-            return fail(ctx, WD_ERR_ARG, "queue_first must be 1..4");
+        if (value != 0 && value != 1 && value != 2 && value != 3 && value != 4 && value != 6 && value != 8)
+            return fail(ctx, WD_ERR_ARG, "queue_first must be 0 (auto), 1, 2, 3, 4, 6 or 8");
         ctx->queue_first = (int)value;
     } else {
         return fail(ctx, WD_ERR_ARG, "unknown option " + n);
