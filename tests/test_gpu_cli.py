@@ -1,0 +1,64 @@
+"""End to end on the GPU: a real run directory (.bcl.gz / .filter files written from the
+synthetic spec) through this package's count_well_duplicates CLI must print what the
+unmodified reference printed for the same run (tests/golden/*.json): stdout byte for byte,
+and the stderr duplicate log line for line."""
+import io
+import os
+from contextlib import redirect_stderr, redirect_stdout
+
+import pytest
+
+from helpers import GOLD, load_fixture, run_cycles
+from well_duplicates_amd import count_well_duplicates as cwd
+from well_duplicates_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _run_dir(tmp_path_factory, name):
+    fx = load_fixture(name)
+    spec = synth.spec_from_dict(fx["spec"])
+    d = tmp_path_factory.mktemp(name)
+    cycles = sorted({c for run in fx["runs"] for c in run_cycles(run)})
+    synth.write_run_dir(spec, str(d), fx["lanes"], fx["tiles"], cycles)
+    return fx, str(d)
+
+
+def _cli(fx, run_dir, run, extra=()):
+    argv = ["-f", os.path.join(GOLD, fx["targets_file"]), "-n", str(fx["n_targets"]),
+            "-l", str(fx["levels"]), "-s", "hiseq_4000", "-r", run_dir,
+            "-t", ",".join(fx["tiles"]), "-i", ",".join(str(l) for l in fx["lanes"])]
+    argv += run["flags"] + list(extra)
+    out, err = io.StringIO(), io.StringIO()
+    with redirect_stdout(out), redirect_stderr(err):
+        assert cwd.main(argv) == 0
+    return out.getvalue(), err.getvalue()
+
+
+@pytest.mark.parametrize("name", ["mid", "mid_subset", "dead_tile", "seven_levels"])
+def test_cli_matches_reference(tmp_path_factory, name):
+    fx, run_dir = _run_dir(tmp_path_factory, name)
+    for run in fx["runs"]:
+        out, err = _cli(fx, run_dir, run)
+        assert out == run["stdout"], (name, run["flags"])
+        keep = ("center seq at", "well seq at", "edit distance:")
+        log = [ln for ln in err.splitlines() if ln.startswith(keep)]
+        if "-q" in run["flags"]:
+            assert err == ""
+        else:
+            assert log == run["dup_log"], (name, run["flags"])
+            assert err.splitlines()[0] == "Reading tile %s in lane %s" % (fx["tiles"][0], fx["lanes"][0])
+
+
+def test_cli_tile_batching_and_errors(tmp_path_factory):
+    fx, run_dir = _run_dir(tmp_path_factory, "dead_tile")
+    run = fx["runs"][0]
+    base, _ = _cli(fx, run_dir, run)
+    one_by_one, _ = _cli(fx, run_dir, run, ["--tile-batch", "1", "--threads", "1"])
+    assert one_by_one == base == run["stdout"]
+    with pytest.raises(AssertionError):                   # -t pattern matching no tile
+        cwd.main(["-f", os.path.join(GOLD, fx["targets_file"]), "-s", "hiseq_4000", "-r", run_dir,
+                  "-t", "9999", "-i", "1", "-q"])
+    with pytest.raises(RuntimeError):                     # tile without files (bcl :131-132)
+        cwd.main(["-f", os.path.join(GOLD, fx["targets_file"]), "-s", "hiseq_4000", "-r", run_dir,
+                  "-t", "1103", "-i", "1", "-q", "--cycles", "0-50", "-l", "5"])

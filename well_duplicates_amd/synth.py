@@ -273,3 +273,42 @@ def spec_from_dict(d: dict) -> SynthSpec:
     d = dict(d)
     d["dead_tiles"] = tuple(d.get("dead_tiles", ()))
     return SynthSpec(**d)
+
+
+def cbcl_file_bytes(tile_planes: dict, filters: dict | None = None, header_size: int = 5681,
+                    compresslevel: int = 1) -> bytes:
+    """One cycle's .cbcl file for several tiles (layout: bcl_direct_reader.py:255-325,
+    cbcl_read.py:19-99): header '<HIBBI' (version 1, header size, 2 base bits, 2 quality
+    bits, 4 bins), 4 x (uint32, uint32) bin table, uint32 tile count, per tile
+    (tile, clusters, uncompressed size, compressed size), 1 byte excluded flag, padding up to
+    header_size, then one gzip member per tile holding 2 wells per byte, low nibble first.
+
+    tile_planes: {tile number: N plane bytes}; only (byte & 3) | (4 if byte else 0)... the
+    nibble written is `byte & 0xF` with zero kept as no-call, so `nibble & 3` is the base.
+    filters: if given, {tile: N filter bytes} and only passing wells are stored
+    (excluded flag = 1, the NovaSeq default).
+    """
+    import gzip
+    import struct as _s
+
+    tiles = sorted(tile_planes)
+    blocks, table = [], b""
+    for t in tiles:
+        plane = np.asarray(tile_planes[t], dtype=np.uint8)
+        # a called base must stay non-zero in 4 bits: keep the base, set a quality bit
+        nib = np.where(plane == 0, 0, (plane & 3) | 4).astype(np.uint8)
+        if filters is not None:
+            nib = nib[(np.asarray(filters[t]) & 1) == 1]
+        n = nib.shape[0]
+        if n % 2:
+            nib = np.concatenate([nib, np.zeros(1, np.uint8)])
+        packed = (nib[0::2] | (nib[1::2] << 4)).astype(np.uint8).tobytes()
+        comp = gzip.compress(packed, compresslevel=compresslevel)
+        blocks.append(comp)
+        table += _s.pack("<IIII", int(t), n, len(packed), len(comp))
+    head = _s.pack("<HIBBI", 1, header_size, 2, 2, 4)
+    head += b"".join(_s.pack("<II", i, i) for i in range(4))
+    head += _s.pack("<I", len(tiles)) + table + bytes([1 if filters is not None else 0])
+    assert len(head) <= header_size
+    head += b"\0" * (header_size - len(head))
+    return head + b"".join(blocks)
