@@ -73,6 +73,7 @@ def main():
     if world > 1:
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
+    from well_duplicates_amd import dist as wdist
     from well_duplicates_amd import synth, workload
     from well_duplicates_amd.scanner import Scanner, TileBatch, MODE_EQ, MODE_HAMMING, MODE_LEVENSHTEIN
 
@@ -132,10 +133,7 @@ def main():
     fence()
     elapsed = time.perf_counter() - t_start
     sc.scan_status()
-    if world > 1:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
+    elapsed = wdist.max_over_ranks(elapsed, world, device="cuda")     # slowest rank
 
     counts = block.cpu().numpy()
     compares_all = int(counts[:, 1:1 + levels].sum())          # sum of Wells over every rank
@@ -165,14 +163,15 @@ def main():
             traffic = tj.get(key, {}).get("hbm_bytes_per_launch")
         except Exception:
             traffic = None
-    roofline = {"bound": "hbm", "kernel": "k_scan", "achieved": round(achieved, 2),
+    kernel_name = "k_scan_q" if (args.mode != "levenshtein" or k < 2) and not args.no_early_exit else "k_scan"
+    roofline = {"bound": "hbm", "kernel": kernel_name, "achieved": round(achieved, 2),
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                 "traffic": traffic, "algorithmic_bytes_per_launch": b_alg,
                 "kernel_ms": round(kern_ms, 5), "launches_timed": launches,
                 "units_per_launch": compares_rank}
 
     # ---- CPU baseline: the oracle on a bounded sample, rank 0 at N = 1 only --------------
-    cpu = None
+    cpu = cpu_py = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import oracle
         n_cpu = max(1, min(args.cpu_tiles, args.tiles))
@@ -181,7 +180,7 @@ def main():
         filters = [tb.download_filter(i) for i in range(n_cpu)]
         reps, t_cpu, out = 0, 0.0, None
         t1 = time.perf_counter()
-        while t_cpu < 10.0 and reps < 50:
+        while t_cpu < 3.0 and reps < 400:                # ~3 s wall x `cores` threads of CPU work
             out = oracle.count_tiles_mt(planes, filters, centre, lvl_off, nbr, mode, k, cores)
             reps += 1
             t_cpu = time.perf_counter() - t1
@@ -198,6 +197,23 @@ def main():
                          "planes already decompressed in RAM (the reference also gunzips and builds Python strings)"
                          % (n_cpu, args.tiles, cpu_compares, reps, t_cpu),
                "parity_checked_tiles": n_cpu}
+        # the faithful single-threaded Python restatement (reference structure: dict of
+        # strings, per-base gather loop, triple compare loop) on a slice of one tile
+        n_py = min(200, T)
+        coords = [[[int(centre[t])]] + [nbr[lvl_off[t, l]:lvl_off[t, l + 1]].tolist() for l in range(levels)]
+                  for t in range(n_py)]
+        wells = [w for c in coords for ring in c for w in ring]
+        pl_bytes = [p.tobytes() for p in planes[0]]
+        t2 = time.perf_counter()
+        seqs = oracle.py_get_seqs(pl_bytes, filters[0].tobytes(), wells)
+        metric = {"eq": oracle.py_hamming, "hamming": oracle.py_hamming,
+                  "levenshtein": oracle.py_levenshtein}[args.mode]
+        stats = oracle.py_count_tile(coords, seqs, levels, metric, k)
+        t_py = time.perf_counter() - t2
+        py_compares = sum(ln for targ in stats for _, ln in targ)
+        cpu_py = {"value": round(py_compares / t_py, 1), "unit": "compares/s", "cores": 1, "kind": "port",
+                  "sample": "first %d targets of 1 tile (%d compares) in %.2f s, pure-Python restatement of "
+                            "get_seqs + the compare loop, planes already gunzipped" % (n_py, py_compares, t_py)}
 
     if rank == 0:
         line = {
@@ -214,6 +230,7 @@ def main():
                        "setup_s": round(setup_s, 1)},
             "roofline": roofline,
             "cpu_baseline": cpu,
+            "cpu_baseline_python": cpu_py,
         }
         print(json.dumps(line))
     tb.free()

@@ -182,6 +182,7 @@ typedef struct wd_synth_spec {
     uint32_t nocall_per_64k, pass_per_64k, plant_per_64k;
     uint32_t filter_noise;
     uint32_t tile_dead;
+    uint32_t plant_far;
 } wd_synth_spec;
 int wd_synth_plane(wd_ctx *ctx, uint8_t *dst_dev, const wd_synth_spec *spec, int lane, int tile,
                    int cycle);

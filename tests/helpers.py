@@ -14,7 +14,7 @@ from well_duplicates_amd import synth                      # noqa: E402
 from well_duplicates_amd.targets import load_targets      # noqa: E402
 
 MODE_ID = {"eq": 0, "hamming": 1, "levenshtein": 2}
-FIXTURES = ["small_list", "mid", "mid_subset", "dead_tile", "seven_levels"]
+FIXTURES = ["small_list", "mid", "mid_subset", "dead_tile", "seven_levels", "far"]
 
 
 @lru_cache(maxsize=None)

@@ -35,7 +35,7 @@ def _cli(fx, run_dir, run, extra=()):
     return out.getvalue(), err.getvalue()
 
 
-@pytest.mark.parametrize("name", ["mid", "mid_subset", "dead_tile", "seven_levels"])
+@pytest.mark.parametrize("name", ["mid", "mid_subset", "dead_tile", "seven_levels", "far"])
 def test_cli_matches_reference(tmp_path_factory, name):
     fx, run_dir = _run_dir(tmp_path_factory, name)
     for run in fx["runs"]:

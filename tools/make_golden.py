@@ -294,6 +294,18 @@ def main():
                   n_targets=160, levels=5, keep=args.keep, targets_origin="mid.targets.list",
                   reuse_targets="mid.targets.list")
 
+    # --- duplicates at every level 1..5 (copies from up to 5 rows away): AccO/AccI columns ---
+    if want("far"):
+        spec = synth.SynthSpec(seed=21, n_clusters=n_mid, row=geo["cols"], plant_per_64k=20000,
+                               plant_far=True, nocall_per_64k=900)
+        text = open(os.path.join(GOLD, "mid.targets.list")).read()
+        cyc = [(5, 45)]
+        make_case(cwd, "far", spec, geo, text, [4], ["2101", "2102", "2103"], cyc,
+                  [variant("hamming", 0, cyc), variant("hamming", 1, cyc),
+                   variant("levenshtein", 2, cyc), variant("levenshtein", 3, cyc)],
+                  n_targets=160, levels=5, keep=args.keep, targets_origin="mid.targets.list",
+                  reuse_targets="mid.targets.list")
+
     # --- 7 levels: targets from this package's generator (the reference's stops at 5) -----
     if want("seven_levels"):
         spec = synth.SynthSpec(seed=8, n_clusters=n_mid, row=geo["cols"], plant_per_64k=9000)

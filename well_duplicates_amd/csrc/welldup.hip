@@ -78,7 +78,7 @@ struct SynthPlaneArgs {
     uint8_t *dst;
     int64_t n, row;
     uint64_t key_here, key_next, key_plant;
-    uint32_t nocall, plant;
+    uint32_t nocall, plant, far;
     int cycle;
 };
 
@@ -88,8 +88,14 @@ __global__ __launch_bounds__(kBlock) void k_synth_plane(SynthPlaneArgs a)
     for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < a.n; i += stride) {
         uint64_t g = mix64(a.key_plant + (uint64_t)i * K_CLUSTER);
         bool planted = (g & 0xFFFF) < a.plant;
-        uint32_t sel = ((uint32_t)(g >> 16) & 0xFFu) % 3u;
-        int64_t delta = sel == 0 ? 1 : (sel == 1 ? a.row : 2 * a.row);
+        int64_t delta;
+        if (a.far) {
+            const uint32_t sel = (uint32_t)(g >> 16) & 7u;
+            delta = sel < 3 ? (int64_t)sel + 1 : (int64_t)(sel - 2) * a.row;
+        } else {
+            const uint32_t sel = ((uint32_t)(g >> 16) & 0xFFu) % 3u;
+            delta = sel == 0 ? 1 : (sel == 1 ? a.row : 2 * a.row);
+        }
         int64_t src = i - delta;
         planted = planted && src >= 0;
         uint8_t b;
@@ -1712,6 +1718,7 @@ int wd_synth_plane(wd_ctx *ctx, uint8_t *dst_dev, const wd_synth_spec *spec, int
     a.key_plant = synth_tile_key(spec, lane, tile, SALT_PLANT);
     a.nocall = spec->nocall_per_64k;
     a.plant = spec->plant_per_64k;
+    a.far = spec->plant_far;
     a.cycle = cycle;
     if (a.n == 0)
         return WD_OK;

@@ -77,6 +77,7 @@ class SynthSpec:
     plant_per_64k: int = 1311          # 2 %
     filter_noise: bool = False         # set filter bit 1 at random (tests `flag & 1`)
     dead_tiles: tuple = ()             # tile numbers whose every cluster fails the filter
+    plant_far: bool = False            # copies from up to 5 rows / 3 wells away (outer levels)
 
     def tile_key(self, lane: int, tile: int, salt: int) -> int:
         return mix64_int(self.seed * K_SEED + lane * K_LANE + tile * K_TILE + salt)
@@ -108,8 +109,15 @@ def plant_info(spec: SynthSpec, lane: int, tile: int, clusters: np.ndarray):
         g = mix64(np.uint64(spec.tile_key(lane, tile, SALT_PLANT))
                   + clusters.astype(np.uint64) * np.uint64(K_CLUSTER))
     planted = (g & np.uint64(0xFFFF)) < np.uint64(spec.plant_per_64k)
-    sel = ((g >> np.uint64(16)) & np.uint64(0xFF)) % np.uint64(3)
-    delta = np.where(sel == 0, 1, np.where(sel == 1, spec.row, 2 * spec.row)).astype(np.int64)
+    if spec.plant_far:
+        # 8 source offsets reaching honeycomb levels 1..5
+        sel = ((g >> np.uint64(16)) & np.uint64(7)).astype(np.int64)
+        table = np.array([1, 2, 3, spec.row, 2 * spec.row, 3 * spec.row, 4 * spec.row,
+                          5 * spec.row], dtype=np.int64)
+        delta = table[sel]
+    else:
+        sel = ((g >> np.uint64(16)) & np.uint64(0xFF)) % np.uint64(3)
+        delta = np.where(sel == 0, 1, np.where(sel == 1, spec.row, 2 * spec.row)).astype(np.int64)
     src = clusters - delta
     planted &= src >= 0
     src = np.where(planted, src, clusters)
