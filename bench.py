@@ -53,6 +53,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-steps", type=int, default=20)
     ap.add_argument("--option", action="append", default=[], help="name=value scanner option")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="collective backend for N > 1: nccl = RCCL over xGMI (default); gloo = "
+                         "rehearsal of the multi-rank logic with several ranks on ONE GPU")
     return ap.parse_args()
 
 
@@ -69,9 +72,15 @@ def main():
 
     import torch
     import torch.distributed as dist
+    rehearsal = args.backend == "gloo"
+    if rehearsal:
+        local_rank = 0                       # every rank shares GPU 0; collectives go through the CPU
     torch.cuda.set_device(local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     from well_duplicates_amd import dist as wdist
     from well_duplicates_amd import synth, workload
@@ -94,8 +103,14 @@ def main():
     # repeated ids (only if --tiles > 96) get distinct lanes so no two tiles share data
     lane_tile = [(lane + 8 * (i // 96), t) for i, t in enumerate(tile_ids)]
 
+    # One explicit stream for everything in a step (scan kernels, torch ops, the collective's
+    # stream dependencies).  The scanner must NOT be left on its own stream here: torch's
+    # zero_/all_reduce would then race with the scan.
+    stream = torch.cuda.Stream()
+    torch.cuda.set_stream(stream)
     sc = Scanner(local_rank)
-    sc.set_stream(torch.cuda.current_stream().cuda_stream)
+    assert stream.cuda_stream != 0
+    sc.set_stream(stream.cuda_stream)
     for opt in args.option:
         name, val = opt.split("=")
         sc.set_option(name, int(val))
@@ -114,8 +129,12 @@ def main():
         if world > 1:
             block.zero_()
         sc.scan_async(tb.tables, args.tiles, L, n_clusters, mode, k, my_rows.data_ptr())
-        if world > 1:
+        if world > 1 and not rehearsal:
             dist.all_reduce(block)          # RCCL int64 sum over xGMI; rows are disjoint
+        elif world > 1:
+            host = block.cpu()
+            dist.all_reduce(host)
+            block.copy_(host)
 
     def fence():
         torch.cuda.synchronize()
@@ -133,7 +152,7 @@ def main():
     fence()
     elapsed = time.perf_counter() - t_start
     sc.scan_status()
-    elapsed = wdist.max_over_ranks(elapsed, world, device="cuda")     # slowest rank
+    elapsed = wdist.max_over_ranks(elapsed, world, device="cpu" if rehearsal else "cuda")   # slowest rank
 
     counts = block.cpu().numpy()
     compares_all = int(counts[:, 1:1 + levels].sum())          # sum of Wells over every rank

@@ -65,13 +65,15 @@ wd_ctx *wd_create(int device_id);
 int wd_create_status(void);
 void wd_destroy(wd_ctx *ctx);
 
-/* Run on a caller-owned HIP stream (hipStream_t, e.g. torch's current stream); NULL
- * returns to the context's own stream. */
+/* Run on a caller-owned HIP stream (hipStream_t, e.g. a torch.cuda.Stream's cuda_stream);
+ * NULL returns to the context's own (non-blocking) stream.  To run on the HIP null stream
+ * itself (torch's default stream has handle 0) use wd_set_option("null_stream", 1). */
 int wd_set_stream(wd_ctx *ctx, void *hip_stream);
 int wd_synchronize(wd_ctx *ctx);
 
 /* Tunables, by name (default): "early_exit" (1), "targets_per_block" (64), "queue_kernel" (1),
- * "queue_first" (0 = from k), "batch_first" (4), "batch_next" (4), "profile" (0).
+ * "queue_first" (0 = from k), "batch_first" (4), "batch_next" (4), "profile" (0),
+ * "null_stream" (0).
  * Unknown names return WD_ERR_ARG. */
 int wd_set_option(wd_ctx *ctx, const char *name, int64_t value);
 int wd_get_option(wd_ctx *ctx, const char *name, int64_t *value);

@@ -1223,6 +1223,13 @@ int wd_set_option(wd_ctx *ctx, const char *name, int64_t value)
         ctx->batch_next = (int)value;
     } else if (n == "profile") {
         ctx->profile = value ? 1 : 0;
+    } else if (n == "null_stream") {
+        // run on the HIP null (legacy default) stream, e.g. to order with a framework that
+        // uses it; 0 returns to the context's own stream
+        if (bind_device(ctx))
+            return WD_ERR_HIP;
+        WD_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        ctx->stream = value ? (hipStream_t) nullptr : ctx->own_stream;
     } else if (n == "queue_kernel") {
         ctx->queue_kernel = value ? 1 : 0;
     } else if (n == "queue_first") {
@@ -1246,6 +1253,7 @@ int wd_get_option(wd_ctx *ctx, const char *name, int64_t *value)
     else if (n == "batch_next") *value = ctx->batch_next;
     else if (n == "profile") *value = ctx->profile;
     else if (n == "queue_kernel") *value = ctx->queue_kernel;
+    else if (n == "null_stream") *value = ctx->stream == nullptr ? 1 : 0;
     else if (n == "queue_first") *value = ctx->queue_first;
     else return fail(ctx, WD_ERR_ARG, "unknown option " + n);
     return WD_OK;
