@@ -14,7 +14,8 @@ from well_duplicates_amd import synth                      # noqa: E402
 from well_duplicates_amd.targets import load_targets      # noqa: E402
 
 MODE_ID = {"eq": 0, "hamming": 1, "levenshtein": 2}
-FIXTURES = ["small_list", "mid", "mid_subset", "dead_tile", "seven_levels", "far"]
+FIXTURES = ["small_list", "mid", "mid_subset", "dead_tile", "seven_levels", "far", "novaseq",
+            "novaseq_all_wells"]
 
 
 @lru_cache(maxsize=None)
@@ -35,14 +36,18 @@ def run_cycles(run):
     return [c for a, b in run["cycles"] for c in range(a, b)]
 
 
-def compact_tile(spec, lane, tile, cycles, centre, nbr):
+def compact_tile(spec, lane, tile, cycles, centre, nbr, excluded_cbcl=False):
     """Planes/filter restricted to the wells the targets touch, plus remapped indices.
 
     The oracle only ever reads those wells, so this is equivalent to full planes and keeps
-    the CPU suite fast (the synthetic bytes are a pure function of (cycle, cluster))."""
+    the CPU suite fast (the synthetic bytes are a pure function of (cycle, cluster)).
+    excluded_cbcl: the run stores only passing wells (NovaSeq .cbcl with the excluded flag),
+    so wells that failed the filter read as no-calls (bcl_direct_reader.py:303-314)."""
     wells = np.unique(np.concatenate([centre, nbr]).astype(np.int64))
     planes = [synth.plane_bytes(spec, lane, int(tile), c, wells) for c in cycles]
     filt = synth.filter_bytes(spec, lane, int(tile), wells)
+    if excluded_cbcl:
+        planes = [np.where(filt & 1, p, 0).astype(np.uint8) for p in planes]
     c2 = np.searchsorted(wells, centre).astype(np.int32)
     n2 = np.searchsorted(wells, nbr).astype(np.int32)
     return planes, filt, c2, n2, wells

@@ -20,13 +20,16 @@ def _run_dir(tmp_path_factory, name):
     spec = synth.spec_from_dict(fx["spec"])
     d = tmp_path_factory.mktemp(name)
     cycles = sorted({c for run in fx["runs"] for c in run_cycles(run)})
-    synth.write_run_dir(spec, str(d), fx["lanes"], fx["tiles"], cycles)
+    if fx.get("cbcl") is None:
+        synth.write_run_dir(spec, str(d), fx["lanes"], fx["tiles"], cycles)
+    else:
+        synth.write_run_dir_cbcl(spec, str(d), fx["lanes"], fx["tiles"], cycles, excluded=fx["cbcl"])
     return fx, str(d)
 
 
 def _cli(fx, run_dir, run, extra=()):
     argv = ["-f", os.path.join(GOLD, fx["targets_file"]), "-n", str(fx["n_targets"]),
-            "-l", str(fx["levels"]), "-s", "hiseq_4000", "-r", run_dir,
+            "-l", str(fx["levels"]), "-s", fx.get("stype", "hiseq_4000"), "-r", run_dir,
             "-t", ",".join(fx["tiles"]), "-i", ",".join(str(l) for l in fx["lanes"])]
     argv += run["flags"] + list(extra)
     out, err = io.StringIO(), io.StringIO()
@@ -35,7 +38,8 @@ def _cli(fx, run_dir, run, extra=()):
     return out.getvalue(), err.getvalue()
 
 
-@pytest.mark.parametrize("name", ["mid", "mid_subset", "dead_tile", "seven_levels", "far"])
+@pytest.mark.parametrize("name", ["mid", "mid_subset", "dead_tile", "seven_levels", "far", "novaseq",
+                                  "novaseq_all_wells"])
 def test_cli_matches_reference(tmp_path_factory, name):
     fx, run_dir = _run_dir(tmp_path_factory, name)
     for run in fx["runs"]:

@@ -70,6 +70,13 @@ def test_golden_fixtures(sc, name):
         if cycles not in batches:
             tb = TileBatch(sc, len(slots), len(cycles), spec.n_clusters)
             tb.fill_synthetic(spec, [(l, int(t)) for l, t in slots], cycles)
+            if fx.get("cbcl"):
+                # excluded-wells CBCL: failed wells read as no-calls (bcl_direct_reader.py:303-314)
+                for i, (l, t) in enumerate(slots):
+                    f = synth.filter_bytes(spec, l, int(t))
+                    planes = [np.where(f & 1, synth.plane_bytes(spec, l, int(t), c), 0).astype(np.uint8)
+                              for c in cycles]
+                    tb.upload_tile(i, planes, f)
             batches[cycles] = tb
         tb = batches[cycles]
         mode, k = MODE_ID[run["mode"]], run["k"]
@@ -140,11 +147,9 @@ def test_all_modes_vs_oracle(sc, L):
     for i, (lane, tile) in enumerate([(1, 1101), (3, 2210)]):
         host.append(compact_tile(spec, lane, tile, cycles, centre, nbr))
     ks = {0: [0], 1: [-1, 0, 1, 2, 3, 7, L - 1, L, L + 5],
-          2: [-1, 0, 1, 2, 3, 4, 5, 6, 7, 9, 12, 13, 16, 17, L - 1, L, L + 3]}
+          2: [-1, 0, 1, 2, 3, 4, 5, 6, 7, 9, 12, 13, 16, 17, 18, 19, 25, L - 2, L - 1, L, L + 3]}
     for mode, klist in ks.items():
         for k in klist:
-            if mode == 2 and 18 <= k < L:
-                continue
             blocks, pt = tb.count(mode, k, per_target=True)
             for i in range(2):
                 planes, filt, c2, n2, _ = host[i]
@@ -245,6 +250,62 @@ def test_low_diversity_stress(sc, kind):
             if kind == "all_nocall" and mode == 0:
                 assert res[1][0][:, 1 + levels:1 + 2 * levels].sum() == res[1][0][:, 1:1 + levels].sum()  # all dups
         tb.free()
+
+
+def _mutate(rng, seq, n_edits):
+    """n_edits random edits (sub / ins / del), then trimmed or padded back to len(seq)."""
+    s = list(seq)
+    for _ in range(n_edits):
+        op = rng.integers(0, 3)
+        pos = int(rng.integers(0, len(s) + 1))
+        if op == 0 and s:
+            s[min(pos, len(s) - 1)] = int(rng.integers(0, 5))
+        elif op == 1:
+            s.insert(pos, int(rng.integers(0, 5)))
+        elif s:
+            del s[min(pos, len(s) - 1)]
+    s = s[:len(seq)]
+    while len(s) < len(seq):
+        s.append(int(rng.integers(0, 5)))
+    return s
+
+
+@pytest.mark.parametrize("L", [7, 20, 50, 64, 101])
+def test_levenshtein_crafted_pairs(sc, L):
+    """Neighbours are random edit scripts (substitutions, insertions, deletions, no-calls) of
+    their centre, 0..7 edits: every band width of the register DP against the oracle's full
+    DP, with uploaded (not generated) planes and thresholds around every H boundary."""
+    rng = np.random.default_rng(1000 + L)
+    T, per = 120, 12
+    n = T * (per + 1)
+    codes = np.zeros((n, L), dtype=np.int64)          # 0..3 bases, 4 = no-call
+    centre = np.arange(T, dtype=np.int32) * (per + 1)
+    nbr = []
+    for t in range(T):
+        c = centre[t]
+        codes[c] = rng.integers(0, 5, L) if t % 3 else rng.integers(0, 2, L)   # low diversity too
+        for j in range(per):
+            codes[c + 1 + j] = _mutate(rng, codes[c].tolist(), int(rng.integers(0, 8)))
+            nbr.append(c + 1 + j)
+    # BCL bytes: no-call = 0, else random quality bits over the base
+    q = rng.integers(1, 41, size=codes.shape)
+    planes_b = np.where(codes == 4, 0, (q << 2) | (codes & 3)).astype(np.uint8)
+    lvl_off = np.zeros((T, 4), dtype=np.int32)
+    for t in range(T):
+        lvl_off[t] = t * per + np.array([0, 3, 7, per])
+    nbr = np.asarray(nbr, dtype=np.int32)
+    filt = np.ones(n, dtype=np.uint8)
+    sc.set_targets(centre, lvl_off, nbr)
+    tb = TileBatch(sc, 1, L, n)
+    planes = [np.ascontiguousarray(planes_b[:, c]) for c in range(L)]
+    tb.upload_tile(0, planes, filt)
+    for mode, ks in ((2, list(range(0, 22)) + [L - 3]), (1, [0, 1, 2, 5, 9])):
+        for k in ks:
+            _, pt = tb.count(mode, k, per_target=True)
+            valid, dups, lens, dist = oracle.count_tile(planes, filt, centre, lvl_off, nbr, mode, k,
+                                                        want_dist=True)
+            assert (pt[0].astype(np.int64) == dups).all(), (L, mode, k)
+    tb.free()
 
 
 def test_errors_and_edges(sc):

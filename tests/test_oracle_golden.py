@@ -33,7 +33,8 @@ def test_oracle_reproduces_reference(name):
             lane = int(lane_rec["lane"])
             got = {}
             for tile in fx["tiles"]:
-                planes, filt, c2, n2, _ = compact_tile(spec, lane, tile, cycles, centre, nbr)
+                planes, filt, c2, n2, _ = compact_tile(spec, lane, tile, cycles, centre, nbr,
+                                                       excluded_cbcl=bool(fx.get("cbcl")))
                 valid, dups, lens, dist = oracle.count_tile(planes, filt, c2, lvl_off, n2,
                                                             mode, k, want_dist=True)
                 got[tile] = lane_dupl_from(valid, dups, lens)

@@ -123,7 +123,8 @@ def count_dups(runs):
 
 
 def make_case(cwd, name, spec, geometry, targets_text, lanes, tiles, cycle_ranges, variants,
-              n_targets, levels, keep=False, targets_origin="reference", reuse_targets=None):
+              n_targets, levels, keep=False, targets_origin="reference", reuse_targets=None,
+              stype="hiseq_4000", cbcl=None):
     """Write the run dir once, run every flag variant, store one JSON."""
     tmp = tempfile.mkdtemp(prefix="wd_golden_")
     try:
@@ -133,7 +134,10 @@ def make_case(cwd, name, spec, geometry, targets_text, lanes, tiles, cycle_range
             x, y = synth.honeycomb_pixels(geometry["rows"], geometry["cols"])
             slocs = synth.slocs_bytes(x, y)
         all_cycles = sorted({c for a, b in cycle_ranges for c in range(a, b)})
-        synth.write_run_dir(spec, run_dir, lanes, tiles, all_cycles, slocs)
+        if cbcl is None:
+            synth.write_run_dir(spec, run_dir, lanes, tiles, all_cycles, slocs)
+        else:
+            synth.write_run_dir_cbcl(spec, run_dir, lanes, tiles, all_cycles, excluded=cbcl, slocs=slocs)
         tpath = os.path.join(tmp, "targets.list")
         with open(tpath, "w") as fh:
             fh.write(targets_text)
@@ -143,7 +147,7 @@ def make_case(cwd, name, spec, geometry, targets_text, lanes, tiles, cycle_range
                 fh.write(targets_text)
         runs = []
         for var in variants:
-            argv = ["-f", tpath, "-n", str(n_targets), "-l", str(levels), "-s", "hiseq_4000",
+            argv = ["-f", tpath, "-n", str(n_targets), "-l", str(levels), "-s", stype,
                     "-r", run_dir, "-t", ",".join(tiles), "-i", ",".join(str(l) for l in lanes)]
             argv += var["flags"]
             out, err, captured, exc = run_reference_count(cwd, argv)
@@ -163,7 +167,8 @@ def make_case(cwd, name, spec, geometry, targets_text, lanes, tiles, cycle_range
             "targets_origin": targets_origin,
             "targets_sha256": hashlib.sha256(targets_text.encode()).hexdigest(),
             "lanes": [int(l) for l in lanes], "tiles": list(tiles),
-            "n_targets": n_targets, "levels": levels,
+            "n_targets": n_targets, "levels": levels, "stype": stype,
+            "cbcl": cbcl,
             "runs": runs,
         }
         with open(os.path.join(GOLD, name + ".json"), "w") as fh:
@@ -230,7 +235,7 @@ def main():
     os.makedirs(GOLD, exist_ok=True)
     tmp = tempfile.mkdtemp(prefix="wd_ref_")
     cwd = import_reference(tmp)
-    want = lambda n: not args.only or args.only == n
+    want = lambda n: not args.only or args.only == n or (args.only == "novaseq" and n.startswith("novaseq"))
 
     if want("report_tables"):
         report_cases(cwd)
@@ -324,6 +329,19 @@ def main():
                    variant("levenshtein", 2, cyc)],
                   n_targets=60, levels=7, keep=args.keep,
                   targets_origin="well_duplicates_amd.cluster_indexes levels=7")
+
+    # --- BASELINE config 4 in small: NovaSeq layout (.cbcl, excluded wells), 7 levels -------
+    if want("novaseq"):
+        spec = synth.SynthSpec(seed=31, n_clusters=n_mid, row=geo["cols"], plant_per_64k=16000,
+                               plant_far=True, nocall_per_64k=1500)
+        text = open(os.path.join(GOLD, "seven_levels.targets.list")).read()
+        cyc = [(0, 30), (60, 80)]
+        for excl, nm in ((True, "novaseq"), (False, "novaseq_all_wells")):
+            make_case(cwd, nm, spec, geo, text, [2], ["1101", "1102", "2678"], cyc,
+                      [variant("hamming", 0, cyc), variant("levenshtein", 2, cyc)],
+                      n_targets=60, levels=7, keep=args.keep,
+                      targets_origin="seven_levels.targets.list",
+                      reuse_targets="seven_levels.targets.list", stype="2678", cbcl=excl)
 
     # --- generator parity: reference prepare_cluster_indexes.py output, two geometries ----
     if want("generator"):

@@ -872,6 +872,131 @@ __global__ __launch_bounds__(kBlock, 6) void k_scan_q(ScanArgs a)
 }
 
 // -------------------------------------------------------------------------------------
+// Generic Levenshtein kernel: any threshold (band half-width H = k/2 > 8), correct not fast
+// -------------------------------------------------------------------------------------
+// One wave per (tile, target), one lane per neighbour slot, 64 slots per pass.  The well's L
+// codes and the banded DP row live in LDS ([.][lane] layout, conflict-free); no early exit.
+// Same recurrence as LevState (row-wise, band |j - i| <= H, saturating at k + 1).
+__host__ __device__ inline size_t lev_generic_lds_bytes(int L, int H)
+{
+    return (size_t)(2 * H + 1) * kWave * sizeof(uint16_t) + (size_t)L * kWave + (size_t)L + 8;
+}
+
+template <bool STRIDED>
+__global__ __launch_bounds__(kWave) void k_scan_lev_generic(ScanArgs a, int H)
+{
+    extern __shared__ uint32_t smem[];
+    const int lane = threadIdx.x;
+    const int levels = a.levels;
+    const int L = a.L;
+    const int k = a.k;
+    const int cap = k + 1;
+    const int W = 2 * H + 1;
+    const int ncnt = 1 + 5 * levels;
+    const int tile = blockIdx.x / a.T;
+    const int t = blockIdx.x - tile * a.T;
+    uint16_t *row = (uint16_t *)smem;
+    uint8_t *wcode = (uint8_t *)(row + (size_t)W * kWave);
+    uint8_t *ccode = wcode + (size_t)L * kWave;
+
+    gbytes filt = as_global(a.filter[tile]);
+    const uint8_t *const *ptab = STRIDED ? nullptr : a.planes + (size_t)tile * L;
+    gbytes base0 = STRIDED ? as_global(a.planes[tile]) : nullptr;
+    const int64_t stride = a.stride;
+    auto plane_ptr = [&](int j) -> gbytes {
+        return STRIDED ? base0 + (int64_t)j * stride : as_global(ptab[j]);
+    };
+
+    const int32_t *off = a.lvl_off + (size_t)t * (levels + 1);
+    const uint32_t c = (uint32_t)a.centre[t];
+    const int off0 = off[0];
+    const int K = off[levels] - off0;
+    uint32_t *opt = a.out_per_target ? a.out_per_target + ((size_t)tile * a.T + t) * levels : nullptr;
+    if (!(__builtin_amdgcn_readfirstlane((uint32_t)filt[c]) & 1u)) {        // :236-237
+        if (opt && lane < levels)
+            opt[lane] = WD_INVALID_TARGET;
+        return;
+    }
+    int my_lo = 0, my_hi = 0;
+    if (lane < levels) {
+        my_lo = off[lane] - off0;
+        my_hi = off[lane + 1] - off0;
+    }
+    if (a.check_empty && __ballot(lane < levels && my_hi <= my_lo)) {         // :249
+        if (lane == 0)
+            atomicOr(a.rare->status, kStatusEmptyLevel);
+        return;
+    }
+    for (int j = 0; j < L; j++) {
+        const uint32_t b = plane_ptr(j)[c];
+        if (lane == 0)
+            ccode[j] = (uint8_t)code_of(b);
+    }
+    __syncthreads();
+    uint32_t my_d = 0;
+    for (int base = 0; base < K; base += kWave) {
+        const int e = base + lane;
+        const bool act = e < K;
+        const uint32_t idx = act ? (uint32_t)a.nbr[off0 + e] : c;
+        for (int j = 0; j < L; j++)
+            wcode[(size_t)j * kWave + lane] = (uint8_t)code_of(plane_ptr(j)[idx]);
+        for (int d = 0; d < W; d++)
+            row[(size_t)d * kWave + lane] = (uint16_t)(d >= H ? min(d - H, cap) : cap);
+        for (int i = 1; i <= L; i++) {
+            const uint32_t ci = ccode[i - 1];
+            int left = cap;
+            for (int d = 0; d < W; d++) {
+                const int j = i + d - H;
+                int v;
+                if (j < 0 || j > L) {
+                    v = cap;
+                } else if (j == 0) {
+                    v = min(i, cap);
+                } else {
+                    v = row[(size_t)d * kWave + lane] + (ci != wcode[(size_t)(j - 1) * kWave + lane] ? 1 : 0);
+                    if (d + 1 < W)
+                        v = min(v, row[(size_t)(d + 1) * kWave + lane] + 1);
+                    v = min(min(v, left + 1), cap);
+                }
+                row[(size_t)d * kWave + lane] = (uint16_t)v;
+                left = v;
+            }
+        }
+        const int dist = row[(size_t)H * kWave + lane];
+        const bool dup = act && dist <= k;
+        const uint64_t m = __ballot(dup);
+        if (m) {
+            if (lane < levels)
+                my_d += __popcll(m & range_mask(my_lo - base, my_hi - base));
+            if (a.log_hits && dup) {
+                const ScanRare r = *a.rare;
+                unsigned long long h = atomicAdd(r.hit_count, 1ull);
+                if ((long long)h < r.hit_cap)
+                    r.hits[h] = wd_hit{tile, t, off0 + e, dist};
+            }
+        }
+    }
+    const uint64_t hm = __ballot(lane < levels && my_d > 0);
+    unsigned long long *ot = a.out_tile + (size_t)tile * ncnt;
+    if (lane < levels) {
+        atomicAdd(&ot[1 + lane], (unsigned long long)(my_hi - my_lo));
+        if (my_d) {
+            atomicAdd(&ot[1 + levels + lane], (unsigned long long)my_d);
+            atomicAdd(&ot[1 + 2 * levels + lane], 1ull);
+        }
+        if (opt)
+            opt[lane] = my_d;
+    }
+    if (lane == 0) {
+        atomicAdd(&ot[0], 1ull);
+        if (hm) {
+            atomicAdd(&ot[1 + 3 * levels + (__ffsll((long long)hm) - 1)], 1ull);
+            atomicAdd(&ot[1 + 4 * levels + (63 - __clzll((long long)hm))], 1ull);
+        }
+    }
+}
+
+// -------------------------------------------------------------------------------------
 // RCCL, bound at run time
 // -------------------------------------------------------------------------------------
 struct Id128 { char b[WD_UNIQUE_ID_BYTES]; };   // ncclUniqueId, passed by value
@@ -1422,8 +1547,10 @@ int wd_scan_async(wd_ctx *ctx, int n_tiles, int L, int mode, int k, const uint8_
         kk = L;
     if (kk < -1)
         kk = -1;
-    if (lev && kk / 2 > 8)
-        return fail(ctx, WD_ERR_UNSUPPORTED, "Levenshtein threshold 18 <= k < L is not implemented yet");
+    const bool lev_generic = lev && kk / 2 > 8;
+    if (lev_generic && lev_generic_lds_bytes(L, kk / 2) > 64 * 1024)
+        return fail(ctx, WD_ERR_UNSUPPORTED,
+                    "Levenshtein threshold k >= 18 with this read length needs more than 64 KB of LDS");
 
     // pointer tables: uniform plane stride -> per-tile base only
     bool strided = L > 0;
@@ -1487,7 +1614,7 @@ int wd_scan_async(wd_ctx *ctx, int n_tiles, int L, int mode, int k, const uint8_
         WD_HIP(ctx, hipMemsetAsync(ctx->d_hit_count, 0, sizeof(unsigned long long), ctx->stream));
 
     const int chunks = (ctx->T + ctx->tpb - 1) / ctx->tpb;
-    const long long nblocks = (long long)chunks * n_tiles;
+    const long long nblocks = lev_generic ? (long long)ctx->T * n_tiles : (long long)chunks * n_tiles;
     if (nblocks > 0x7FFFFFFFll)
         return fail(ctx, WD_ERR_UNSUPPORTED, "grid too large; raise targets_per_block");
     dim3 grid((unsigned)nblocks);
@@ -1515,6 +1642,13 @@ int wd_scan_async(wd_ctx *ctx, int n_tiles, int L, int mode, int k, const uint8_
             launch_ham<true>(ctx, a, grid);
         else
             launch_ham<false>(ctx, a, grid);
+    } else if (lev_generic) {
+        const int h = kk / 2;
+        const size_t lds = lev_generic_lds_bytes(L, h);
+        if (strided)
+            hipLaunchKernelGGL((k_scan_lev_generic<true>), grid, dim3(kWave), lds, ctx->stream, a, h);
+        else
+            hipLaunchKernelGGL((k_scan_lev_generic<false>), grid, dim3(kWave), lds, ctx->stream, a, h);
     } else {
         const int h = kk / 2;
         if (h <= 1) launch_lev<1>(ctx, a, grid, strided);

@@ -271,6 +271,36 @@ def write_run_dir(spec: SynthSpec, run_dir: str, lanes, tiles, cycles, slocs: by
                     fh.write(bcl_file_bytes(payload))
 
 
+def write_run_dir_cbcl(spec: SynthSpec, run_dir: str, lanes, tiles, cycles, excluded: bool = True,
+                       slocs: bytes | None = None) -> None:
+    """NovaSeq-style run directory: per cycle and lane one `L00<lane>_<surface>.cbcl` holding
+    every tile of that surface (bcl_direct_reader.py:137, :255-325), plus the .filter files."""
+    import os
+
+    inten = os.path.join(run_dir, "Data", "Intensities")
+    os.makedirs(inten, exist_ok=True)
+    if slocs is not None:
+        with open(os.path.join(inten, "s.locs"), "wb") as fh:
+            fh.write(slocs)
+    for lane in lanes:
+        lname = "L%03d" % int(lane)
+        ldir = os.path.join(inten, "BaseCalls", lname)
+        os.makedirs(ldir, exist_ok=True)
+        filters = {int(t): filter_bytes(spec, int(lane), int(t)) for t in tiles}
+        for t in tiles:
+            with open(os.path.join(ldir, "s_%d_%s.filter" % (int(lane), t)), "wb") as fh:
+                fh.write(filter_file_bytes(filters[int(t)]))
+        for cyc in cycles:
+            cdir = os.path.join(ldir, "C%d.1" % (cyc + 1))
+            os.makedirs(cdir, exist_ok=True)
+            for surface in sorted({str(t)[0] for t in tiles}):
+                mine = [int(t) for t in tiles if str(t)[0] == surface]
+                planes = {t: plane_bytes(spec, int(lane), t, cyc) for t in mine}
+                flt = {t: filters[t] for t in mine} if excluded else None
+                with open(os.path.join(cdir, "%s_%s.cbcl" % (lname, surface)), "wb") as fh:
+                    fh.write(cbcl_file_bytes(planes, flt))
+
+
 def spec_to_dict(spec: SynthSpec) -> dict:
     d = dict(spec.__dict__)
     d["dead_tiles"] = list(spec.dead_tiles)
