@@ -76,7 +76,13 @@ def main():
     if rehearsal:
         local_rank = 0                       # every rank shares GPU 0; collectives go through the CPU
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    # WD_BENCH_FORCE_DIST=1 exercises the RCCL code path with a single rank (1-GPU boxes)
+    use_dist = world > 1 or os.environ.get("WD_BENCH_FORCE_DIST") == "1"
+    if use_dist:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         if rehearsal:
             dist.init_process_group("gloo")
         else:
@@ -126,19 +132,19 @@ def main():
     my_rows = block[rank * args.tiles:(rank + 1) * args.tiles]
 
     def step():
-        if world > 1:
+        if use_dist:
             block.zero_()
         sc.scan_async(tb.tables, args.tiles, L, n_clusters, mode, k, my_rows.data_ptr())
-        if world > 1 and not rehearsal:
+        if use_dist and not rehearsal:
             dist.all_reduce(block)          # RCCL int64 sum over xGMI; rows are disjoint
-        elif world > 1:
+        elif use_dist:
             host = block.cpu()
             dist.all_reduce(host)
             block.copy_(host)
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -254,7 +260,7 @@ def main():
         print(json.dumps(line))
     tb.free()
     sc.close()
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

@@ -360,6 +360,34 @@ def test_errors_and_edges(sc):
     tb.free()
 
 
+def test_dense_all_centres_small(sc):
+    """BASELINE config 5 in small: every well of a tile is a centre, 3 levels, 150 bp."""
+    from well_duplicates_amd import workload
+    rows, cols, levels, L = 40, 60, 3, 150
+    n = rows * cols
+    x, y = synth.honeycomb_pixels(rows, cols)
+    centre, lvl_off, nbr = workload.targets_to_csr(cluster_indexes.generate(x, y, range(n), levels))
+    assert centre.shape[0] == n and 30 <= (lvl_off[:, -1] - lvl_off[:, 0]).max() <= 36
+    spec = synth.SynthSpec(seed=12, n_clusters=n, row=cols, plant_per_64k=3000, plant_far=True)
+    sc.set_targets(centre, lvl_off, nbr)
+    tiles = [(1, 1101), (2, 1101)]
+    tb = TileBatch(sc, 2, L, n)
+    tb.fill_synthetic(spec, tiles, list(range(L)))
+    for mode, k in ((0, 0), (1, 3), (2, 2)):
+        blocks, pt = tb.count(mode, k, per_target=True)
+        for i, (lane, tile) in enumerate(tiles):
+            planes = [synth.plane_bytes(spec, lane, tile, c) for c in range(L)]
+            filt = synth.filter_bytes(spec, lane, tile)
+            valid, dups, lens, _ = oracle.count_tile(planes, filt, centre, lvl_off, nbr, mode, k)
+            want = np.where(valid[:, None] == 1, dups, -1)
+            got = pt[i].astype(np.int64)
+            got[got == INVALID_TARGET] = -1
+            assert (got == want).all(), (mode, k)
+            assert (blocks_to_reference(blocks[i], levels) == oracle.tally_tile(valid, dups, lens)).all()
+        assert blocks[:, 1 + levels:1 + 2 * levels].sum() > 0
+    tb.free()
+
+
 def test_fresh_context_requires_targets():
     s = Scanner(0)
     with pytest.raises(RuntimeError):
