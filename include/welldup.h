@@ -19,6 +19,7 @@
  *       WD_ERR_INDEX        -> IndexError       (bcl_direct_reader.py:186-192)
  *       WD_ERR_EMPTY_LEVEL  -> AssertionError   (count_well_duplicates.py:249)
  *       WD_ERR_ARG          -> ValueError
+ *       WD_ERR_NO_WELLS     -> RuntimeError     (prepare_cluster_indexes.py:70-76)
  *       everything else     -> RuntimeError
  */
 #ifndef WELLDUP_H
@@ -40,6 +41,7 @@ extern "C" {
 #define WD_ERR_STATE (-6)
 #define WD_ERR_UNSUPPORTED (-7)
 #define WD_ERR_COMM (-8)
+#define WD_ERR_NO_WELLS (-9)
 
 /* Compare modes.  The reference counts a duplicate when dist <= edit_distance
  * (count_well_duplicates.py:258) with dist = Levenshtein.distance, or Levenshtein.hamming
@@ -98,6 +100,29 @@ int wd_memset(wd_ctx *ctx, void *dst_dev, int value, size_t bytes);
  */
 int wd_set_targets(wd_ctx *ctx, int T, int levels, const int32_t *centre,
                    const int32_t *lvl_off, const int32_t *nbr);
+
+/*
+ * Replaces the index producer: get_indexes()/yield_coords() of prepare_cluster_indexes.py
+ * (:38-78, :99-116) for a list of centre wells, or for every well (centres == NULL: the
+ * all-centres mode of BASELINE config 5, out of reach of the 70 ms/target reference).
+ *
+ *   x, y       host arrays of n pixel coordinates as the reference decodes them from s.locs:
+ *              int(v * 10 + 1000.5) (:110-112).
+ *   centres    host array of n_centres well indices (targets, in output order) or NULL.
+ *   max_dists  levels+1 increasing pixel radii; ring r (0-based) holds wells with
+ *              max_dists[r] < dist <= max_dists[r+1] (:61-63; the reference's table is
+ *              {1,22,42,62,82,102}).  Only records max(0, c-20000) .. c+20001 are examined
+ *              (:52-67) and every ring is emitted in ascending index order, like the
+ *              reference's scan.  A centre with an empty ring fails the call with
+ *              WD_ERR_NO_WELLS (:70-76).
+ * On success the result is installed as the context's targets (as wd_set_targets) and stays
+ * on the GPU; wd_targets_info / wd_get_targets read it back, e.g. to write the targets file.
+ */
+int wd_targets_from_coords(wd_ctx *ctx, const int32_t *x, const int32_t *y, int64_t n,
+                           const int32_t *centres, int64_t n_centres, int levels,
+                           const int32_t *max_dists, int64_t *P_out);
+int wd_targets_info(wd_ctx *ctx, int *T, int *levels, int64_t *P);
+int wd_get_targets(wd_ctx *ctx, int32_t *centre, int32_t *lvl_off, int32_t *nbr);
 
 /* ---- the scan ---------------------------------------------------------------------- */
 /*

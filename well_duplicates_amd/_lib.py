@@ -18,8 +18,8 @@ INCLUDE = os.path.join(REPO, "include")
 LIB_PATH = os.environ.get("WELLDUP_LIB") or os.path.join(HERE, "libwelldup.so")
 
 OK = 0
-ERR_ARG, ERR_INDEX, ERR_EMPTY_LEVEL, ERR_HIP, ERR_NOMEM, ERR_STATE, ERR_UNSUPPORTED, ERR_COMM = \
-    -1, -2, -3, -4, -5, -6, -7, -8
+ERR_ARG, ERR_INDEX, ERR_EMPTY_LEVEL, ERR_HIP, ERR_NOMEM, ERR_STATE, ERR_UNSUPPORTED, ERR_COMM, \
+    ERR_NO_WELLS = -1, -2, -3, -4, -5, -6, -7, -8, -9
 MODE_EQ, MODE_HAMMING, MODE_LEVENSHTEIN = 0, 1, 2
 MAX_LEVELS = 32
 INVALID_TARGET = 0xFFFFFFFF
@@ -62,6 +62,9 @@ PROTOTYPES = {
     "wd_memcpy_d2h": (_i, [_vp, _vp, _vp, _sz]),
     "wd_memset": (_i, [_vp, _vp, _i, _sz]),
     "wd_set_targets": (_i, [_vp, _i, _i, _vp, _vp, _vp]),
+    "wd_targets_from_coords": (_i, [_vp, _vp, _vp, _i64, _vp, _i64, _i, _vp, ctypes.POINTER(_i64)]),
+    "wd_targets_info": (_i, [_vp, ctypes.POINTER(_i), ctypes.POINTER(_i), ctypes.POINTER(_i64)]),
+    "wd_get_targets": (_i, [_vp, _vp, _vp, _vp]),
     "wd_count_tiles": (_i, [_vp, _i, _i, _i, _i, _pp, _pp, _i64, _vp, _vp]),
     "wd_scan_async": (_i, [_vp, _i, _i, _i, _i, _pp, _pp, _i64, _vp, _vp]),
     "wd_scan_status": (_i, [_vp]),

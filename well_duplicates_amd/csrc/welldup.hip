@@ -997,6 +997,95 @@ __global__ __launch_bounds__(kWave) void k_scan_lev_generic(ScanArgs a, int H)
 }
 
 // -------------------------------------------------------------------------------------
+// Neighbour-index generator (the producer of the targets): prepare_cluster_indexes.py on device
+// -------------------------------------------------------------------------------------
+// get_indexes() (prepare_cluster_indexes.py:38-78) scans records max(0, c-20000) .. c+20001
+// and bins each by pixel distance to the centre: ring r holds md[r] < dist <= md[r+1], compared
+// here on exact integer squares.  One block per centre; two launches: count per (centre,
+// ring), host prefix sum, then fill - matches are collected in LDS and ranked by (ring, index)
+// so every ring comes out in ascending index order, as the reference's scan emits it.
+constexpr int kGenWindow = 20000;       // MAX_SEARCH_AREA (:43)
+constexpr int kGenMaxMatches = 2048;
+
+struct GenArgs {
+    const int32_t *x, *y;
+    const int32_t *centres;   // nullable: centre i is well i
+    int64_t n;
+    int n_centres;
+    int levels;
+    int md2[kMaxLevels + 1];  // squared ring boundaries
+    int32_t *counts;          // [n_centres][levels]            (pass 1 output)
+    const int32_t *lvl_off;   // [n_centres][levels+1] absolute (pass 2 input)
+    int32_t *nbr;             // pass 2 output
+    uint32_t *status;
+};
+
+template <bool FILL>
+__global__ __launch_bounds__(kBlock) void k_gen_rings(GenArgs a)
+{
+    __shared__ uint32_t s_cnt[kMaxLevels];
+    __shared__ uint32_t s_n;
+    __shared__ int32_t s_idx[FILL ? kGenMaxMatches : 1];
+    __shared__ uint8_t s_lev[FILL ? kGenMaxMatches : 1];
+    const int t = blockIdx.x;
+    const int64_t c = a.centres ? (int64_t)a.centres[t] : (int64_t)t;
+    const int levels = a.levels;
+    if (threadIdx.x < kMaxLevels)
+        s_cnt[threadIdx.x] = 0;
+    if (threadIdx.x == 0)
+        s_n = 0;
+    __syncthreads();
+    const int cx = a.x[c], cy = a.y[c];
+    const int64_t lo = c > kGenWindow ? c - kGenWindow : 0;
+    const int64_t hi = min(a.n, c + kGenWindow + 2);        // the record at c+20001 is examined (:66)
+    const int far2 = a.md2[levels];
+    const int near2 = a.md2[0];
+    for (int64_t j = lo + threadIdx.x; j < hi; j += kBlock) {
+        const int64_t dx = (int64_t)a.x[j] - cx, dy = (int64_t)a.y[j] - cy;
+        const int64_t d2l = dx * dx + dy * dy;
+        if (d2l > far2 || d2l <= near2)
+            continue;
+        const int d2 = (int)d2l;
+        int lev = 0;
+        for (int r = 1; r < levels; r++)
+            lev += d2 > a.md2[r] ? 1 : 0;
+        if (FILL) {
+            const uint32_t pos = atomicAdd(&s_n, 1u);
+            if (pos < kGenMaxMatches) {
+                s_idx[pos] = (int32_t)j;
+                s_lev[pos] = (uint8_t)lev;
+            }
+        } else {
+            atomicAdd(&s_cnt[lev], 1u);
+        }
+    }
+    __syncthreads();
+    if (!FILL) {
+        if (threadIdx.x < levels) {
+            a.counts[(size_t)t * levels + threadIdx.x] = (int32_t)s_cnt[threadIdx.x];
+            if (s_cnt[threadIdx.x] == 0)
+                atomicOr(a.status, 2u);                       // :70-76 RuntimeError
+        }
+        return;
+    }
+    const uint32_t m = s_n;
+    if (m > kGenMaxMatches) {
+        if (threadIdx.x == 0)
+            atomicOr(a.status, 4u);
+        return;
+    }
+    const int32_t *off = a.lvl_off + (size_t)t * (levels + 1);
+    for (uint32_t i = threadIdx.x; i < m; i += kBlock) {
+        const int32_t me = s_idx[i];
+        const int lev = s_lev[i];
+        int rank = 0;                                         // matches of my ring with a smaller index
+        for (uint32_t q = 0; q < m; q++)
+            rank += (s_lev[q] == lev && s_idx[q] < me) ? 1 : 0;
+        a.nbr[off[lev] + rank] = me;
+    }
+}
+
+// -------------------------------------------------------------------------------------
 // RCCL, bound at run time
 // -------------------------------------------------------------------------------------
 struct Id128 { char b[WD_UNIQUE_ID_BYTES]; };   // ncclUniqueId, passed by value
@@ -1237,6 +1326,7 @@ const char *wd_strerror(int code)
     case WD_ERR_STATE: return "call out of order (targets not set?)";
     case WD_ERR_UNSUPPORTED: return "unsupported parameter combination";
     case WD_ERR_COMM: return "RCCL error";
+    case WD_ERR_NO_WELLS: return "a cluster has no wells at some level";
     default: return "unknown error";
     }
 }
@@ -1777,6 +1867,167 @@ int wd_profile_reset(wd_ctx *ctx)
     drain_events(ctx);
     ctx->prof_ms = 0.0;
     ctx->prof_launches = 0;
+    return WD_OK;
+}
+
+// ---- targets from coordinates ----------------------------------------------------------
+int wd_targets_from_coords(wd_ctx *ctx, const int32_t *x, const int32_t *y, int64_t n,
+                           const int32_t *centres, int64_t n_centres, int levels,
+                           const int32_t *max_dists, int64_t *P_out)
+{
+    if (!ctx || !x || !y || n <= 0 || levels < 1 || levels > kMaxLevels || !max_dists)
+        return fail(ctx, WD_ERR_ARG, "bad coordinates, levels or ring table");
+    if (!centres)
+        n_centres = n;
+    if (n_centres < 0 || n_centres > 0x7FFFFFFF)
+        return fail(ctx, WD_ERR_ARG, "bad number of centres");
+    for (int r = 0; r <= levels; r++)
+        if (max_dists[r] < 0 || max_dists[r] > 30000 || (r && max_dists[r] <= max_dists[r - 1]))
+            return fail(ctx, WD_ERR_ARG, "ring boundaries must be increasing and <= 30000");
+    if (centres)
+        for (int64_t i = 0; i < n_centres; i++)
+            if (centres[i] < 0 || centres[i] >= n)
+                return fail(ctx, WD_ERR_INDEX, "centre outside the s.locs table");
+    if (bind_device(ctx))
+        return WD_ERR_HIP;
+    WD_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    const int T = (int)n_centres;
+    int32_t *d_x = nullptr, *d_y = nullptr, *d_c = nullptr, *d_counts = nullptr;
+    int32_t *d_off = nullptr, *d_nbr = nullptr, *d_centre = nullptr;
+    auto cleanup = [&]() {
+        (void)hipFree(d_x); (void)hipFree(d_y); (void)hipFree(d_c); (void)hipFree(d_counts);
+    };
+    auto bail = [&](int code, const std::string &msg) {
+        cleanup();
+        (void)hipFree(d_off); (void)hipFree(d_nbr); (void)hipFree(d_centre);
+        return fail(ctx, code, msg);
+    };
+#define WD_GEN_HIP(call)                                                                  \
+    do {                                                                                  \
+        hipError_t e_ = (call);                                                           \
+        if (e_ != hipSuccess)                                                             \
+            return bail(e_ == hipErrorOutOfMemory ? WD_ERR_NOMEM : WD_ERR_HIP,            \
+                        std::string(#call) + ": " + hipGetErrorString(e_));               \
+    } while (0)
+    WD_GEN_HIP(hipMalloc((void **)&d_x, (size_t)n * 4));
+    WD_GEN_HIP(hipMalloc((void **)&d_y, (size_t)n * 4));
+    WD_GEN_HIP(hipMemcpy(d_x, x, (size_t)n * 4, hipMemcpyHostToDevice));
+    WD_GEN_HIP(hipMemcpy(d_y, y, (size_t)n * 4, hipMemcpyHostToDevice));
+    WD_GEN_HIP(hipMalloc((void **)&d_centre, std::max<size_t>(1, T) * 4));
+    if (centres) {
+        WD_GEN_HIP(hipMemcpy(d_centre, centres, (size_t)T * 4, hipMemcpyHostToDevice));
+        d_c = nullptr;
+    } else {
+        std::vector<int32_t> iota((size_t)T);
+        for (int i = 0; i < T; i++)
+            iota[i] = i;
+        WD_GEN_HIP(hipMemcpy(d_centre, iota.data(), (size_t)T * 4, hipMemcpyHostToDevice));
+    }
+    WD_GEN_HIP(hipMalloc((void **)&d_counts, std::max<size_t>(1, (size_t)T * levels) * 4));
+    WD_GEN_HIP(hipMemsetAsync(ctx->d_status, 0, sizeof(uint32_t), ctx->stream));
+    GenArgs a;
+    a.x = d_x;
+    a.y = d_y;
+    a.centres = centres ? d_centre : nullptr;
+    a.n = n;
+    a.n_centres = T;
+    a.levels = levels;
+    for (int r = 0; r <= levels; r++)
+        a.md2[r] = max_dists[r] * max_dists[r];
+    a.counts = d_counts;
+    a.lvl_off = nullptr;
+    a.nbr = nullptr;
+    a.status = ctx->d_status;
+    std::vector<int32_t> off((size_t)T * (levels + 1) + 1, 0);
+    int64_t P = 0;
+    if (T > 0) {
+        hipLaunchKernelGGL((k_gen_rings<false>), dim3(T), dim3(kBlock), 0, ctx->stream, a);
+        WD_GEN_HIP(hipGetLastError());
+        std::vector<int32_t> counts((size_t)T * levels);
+        WD_GEN_HIP(hipMemcpyAsync(counts.data(), d_counts, counts.size() * 4, hipMemcpyDeviceToHost, ctx->stream));
+        WD_GEN_HIP(hipMemcpyAsync(ctx->h_status, ctx->d_status, 4, hipMemcpyDeviceToHost, ctx->stream));
+        WD_GEN_HIP(hipStreamSynchronize(ctx->stream));
+        if (*ctx->h_status & 2u) {
+            (void)hipMemsetAsync(ctx->d_status, 0, sizeof(uint32_t), ctx->stream);
+            return bail(WD_ERR_NO_WELLS, "Got no wells for some cluster at some level");
+        }
+        for (int t = 0; t < T; t++) {
+            for (int l = 0; l < levels; l++) {
+                off[(size_t)t * (levels + 1) + l] = (int32_t)P;
+                P += counts[(size_t)t * levels + l];
+                if (P > 0x7FFFFFFF)
+                    return bail(WD_ERR_UNSUPPORTED, "more than 2^31 neighbour slots");
+            }
+            off[(size_t)t * (levels + 1) + levels] = (int32_t)P;
+        }
+    }
+    WD_GEN_HIP(hipMalloc((void **)&d_off, std::max<size_t>(1, (size_t)T * (levels + 1)) * 4));
+    WD_GEN_HIP(hipMalloc((void **)&d_nbr, std::max<int64_t>(1, P) * 4));
+    if (T > 0) {
+        WD_GEN_HIP(hipMemcpy(d_off, off.data(), (size_t)T * (levels + 1) * 4, hipMemcpyHostToDevice));
+        a.lvl_off = d_off;
+        a.nbr = d_nbr;
+        hipLaunchKernelGGL((k_gen_rings<true>), dim3(T), dim3(kBlock), 0, ctx->stream, a);
+        WD_GEN_HIP(hipGetLastError());
+        WD_GEN_HIP(hipMemcpyAsync(ctx->h_status, ctx->d_status, 4, hipMemcpyDeviceToHost, ctx->stream));
+        WD_GEN_HIP(hipStreamSynchronize(ctx->stream));
+        if (*ctx->h_status & 4u) {
+            (void)hipMemsetAsync(ctx->d_status, 0, sizeof(uint32_t), ctx->stream);
+            return bail(WD_ERR_UNSUPPORTED, "a target has more than 2048 wells inside the outermost ring");
+        }
+    }
+#undef WD_GEN_HIP
+    cleanup();
+    // install as the context's targets (as wd_set_targets would)
+    (void)hipFree(ctx->d_centre);
+    (void)hipFree(ctx->d_lvl_off);
+    (void)hipFree(ctx->d_nbr);
+    ctx->d_centre = d_centre;
+    ctx->d_lvl_off = d_off;
+    ctx->d_nbr = d_nbr;
+    ctx->T = T;
+    ctx->levels = levels;
+    ctx->P = P;
+    ctx->idx_min = 0;
+    ctx->idx_max = n - 1 >= 0 && T > 0 ? n - 1 : -1;   // every emitted index lies inside the table
+    ctx->has_empty_level = false;
+    ctx->k_max = 0;
+    for (int t = 0; t < T; t++)
+        ctx->k_max = std::max<int64_t>(ctx->k_max, (int64_t)off[(size_t)t * (levels + 1) + levels] -
+                                                        off[(size_t)t * (levels + 1)]);
+    ctx->has_targets = true;
+    if (P_out)
+        *P_out = P;
+    return WD_OK;
+}
+
+int wd_targets_info(wd_ctx *ctx, int *T, int *levels, int64_t *P)
+{
+    if (!ctx)
+        return WD_ERR_ARG;
+    if (!ctx->has_targets)
+        return fail(ctx, WD_ERR_STATE, "no targets set");
+    if (T) *T = ctx->T;
+    if (levels) *levels = ctx->levels;
+    if (P) *P = ctx->P;
+    return WD_OK;
+}
+
+int wd_get_targets(wd_ctx *ctx, int32_t *centre, int32_t *lvl_off, int32_t *nbr)
+{
+    if (!ctx)
+        return WD_ERR_ARG;
+    if (!ctx->has_targets)
+        return fail(ctx, WD_ERR_STATE, "no targets set");
+    if (bind_device(ctx))
+        return WD_ERR_HIP;
+    WD_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (centre && ctx->T)
+        WD_HIP(ctx, hipMemcpy(centre, ctx->d_centre, (size_t)ctx->T * 4, hipMemcpyDeviceToHost));
+    if (lvl_off && ctx->T)
+        WD_HIP(ctx, hipMemcpy(lvl_off, ctx->d_lvl_off, (size_t)ctx->T * (ctx->levels + 1) * 4, hipMemcpyDeviceToHost));
+    if (nbr && ctx->P)
+        WD_HIP(ctx, hipMemcpy(nbr, ctx->d_nbr, (size_t)ctx->P * 4, hipMemcpyDeviceToHost));
     return WD_OK;
 }
 

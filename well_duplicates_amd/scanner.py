@@ -133,6 +133,40 @@ class Scanner:
             lvl_off.ctypes.data_as(ctypes.c_void_p), nbr.ctypes.data_as(ctypes.c_void_p)))
         self.T, self.levels = T, levels
 
+    def targets_from_coords(self, x, y, centres=None, levels=5, max_dists=None):
+        """Neighbour rings on the device (prepare_cluster_indexes.py:38-78 semantics) for the
+        given centre wells, or for every well when `centres` is None.  The result becomes the
+        scanner's targets; returns (T, P)."""
+        from .cluster_indexes import max_dists_for
+        x = np.ascontiguousarray(x, dtype=np.int32)
+        y = np.ascontiguousarray(y, dtype=np.int32)
+        md = np.ascontiguousarray(max_dists if max_dists is not None else max_dists_for(levels),
+                                  dtype=np.int32)
+        if md.shape[0] != levels + 1:
+            raise ValueError("max_dists must hold levels + 1 radii")
+        c = None if centres is None else np.ascontiguousarray(centres, dtype=np.int32)
+        P = ctypes.c_int64()
+        self._ck(self._lib.wd_targets_from_coords(
+            self._ctx, x.ctypes.data_as(ctypes.c_void_p), y.ctypes.data_as(ctypes.c_void_p),
+            x.shape[0], c.ctypes.data_as(ctypes.c_void_p) if c is not None else None,
+            0 if c is None else c.shape[0], levels, md.ctypes.data_as(ctypes.c_void_p),
+            ctypes.byref(P)))
+        self.T = x.shape[0] if c is None else c.shape[0]
+        self.levels = levels
+        return self.T, P.value
+
+    def get_targets(self):
+        """Download the resident targets as (centre, lvl_off, nbr) int32 arrays."""
+        T, lv, P = ctypes.c_int(), ctypes.c_int(), ctypes.c_int64()
+        self._ck(self._lib.wd_targets_info(self._ctx, ctypes.byref(T), ctypes.byref(lv), ctypes.byref(P)))
+        centre = np.zeros(T.value, dtype=np.int32)
+        lvl_off = np.zeros((T.value, lv.value + 1), dtype=np.int32)
+        nbr = np.zeros(P.value, dtype=np.int32)
+        self._ck(self._lib.wd_get_targets(self._ctx, centre.ctypes.data_as(ctypes.c_void_p),
+                                          lvl_off.ctypes.data_as(ctypes.c_void_p),
+                                          nbr.ctypes.data_as(ctypes.c_void_p)))
+        return centre, lvl_off, nbr
+
     # ------------------------------------------------------------------ scan
     @staticmethod
     def _tables(planes, filters, L):
