@@ -15,7 +15,7 @@ from well_duplicates_amd.scanner import INVALID_TARGET, Scanner, TileBatch
 pytestmark = pytest.mark.gpu
 
 DEFAULT_OPTIONS = (("early_exit", 1), ("batch_first", 4), ("batch_next", 4), ("targets_per_block", 32),
-                   ("queue_kernel", 1), ("queue_first", 0))
+                   ("queue_kernel", 1), ("queue_first", 0), ("dense_kernel", -1))
 
 
 @pytest.fixture(scope="module")
@@ -373,11 +373,14 @@ def test_dense_all_centres_small(sc):
     tiles = [(1, 1101), (2, 1101)]
     tb = TileBatch(sc, 2, L, n)
     tb.fill_synthetic(spec, tiles, list(range(L)))
-    for mode, k in ((0, 0), (1, 3), (2, 2)):
+    host = [([synth.plane_bytes(spec, lane, tile, c) for c in range(L)],
+             synth.filter_bytes(spec, lane, tile)) for lane, tile in tiles]
+    for mode, k, dense in ((0, 0, 1), (0, 0, 0), (1, 1, 1), (1, 2, 1), (1, 3, 1), (2, 2, 1)):
+        sc.set_option("dense_kernel", dense)      # lane-per-target kernel vs the queue kernel
         blocks, pt = tb.count(mode, k, per_target=True)
+        sc.set_option("dense_kernel", -1)
         for i, (lane, tile) in enumerate(tiles):
-            planes = [synth.plane_bytes(spec, lane, tile, c) for c in range(L)]
-            filt = synth.filter_bytes(spec, lane, tile)
+            planes, filt = host[i]
             valid, dups, lens, _ = oracle.count_tile(planes, filt, centre, lvl_off, nbr, mode, k)
             want = np.where(valid[:, None] == 1, dups, -1)
             got = pt[i].astype(np.int64)

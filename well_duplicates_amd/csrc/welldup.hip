@@ -150,6 +150,8 @@ struct ScanArgs {
     unsigned long long *out_tile;   // [n_tiles][1 + 5*levels]
     uint32_t *out_per_target;       // nullable [n_tiles][T][levels]
     const struct ScanRare *rare;    // rarely-touched arguments, read only on the rare paths
+    const int32_t *nbr_t;           // dense kernel: neighbour lists transposed per 64-target group
+    const long long *gbase;         // dense kernel: start of each group's block in nbr_t
     int T, levels, L, k, tpb, early, check_empty, log_hits;
 };
 
@@ -552,6 +554,147 @@ constexpr int kPass = 127;
 constexpr int kQCap = 256;          // >= kPass: after a drain one pass always fits
 constexpr int kMaxPasses = 4;       // host falls back to k_scan for targets with more slots
 
+// ---- survivor queue shared by k_scan_q and k_scan_dense -------------------------------
+// A queue entry is {well index, tag}: tag = target-in-block << 24 | mismatches << 16 | slot.
+struct QEnv {
+    const int32_t *s_centre;      // LDS: centre index of each target of the block
+    const int32_t *s_off;         // LDS: ring offsets, levels + 1 per target
+    uint32_t *s_d;                // LDS: per-target per-level duplicate counters
+    gbytes base0;                 // strided layout: cycle 0 plane of this tile
+    const uint8_t *const *ptab;   // pointer-table layout: this tile's L plane pointers
+    int64_t stride;
+    const ScanRare *rare;
+    int levels, L, k, tile, t_first, log_hits;
+};
+
+template <bool STRIDED>
+__device__ inline gbytes q_plane(const QEnv &v, int j)
+{
+    return STRIDED ? v.base0 + (int64_t)j * v.stride : as_global(v.ptab[j]);
+}
+
+// a duplicate found: bump its target's per-level counter (and the optional hit log)
+__device__ inline void q_record_dup(const QEnv &v, int tl, int e, int dist)
+{
+    const int32_t *o = v.s_off + tl * (v.levels + 1);
+    const int rel0 = o[0];
+    int lev = 0;
+    for (int l = 1; l < v.levels; l++)
+        lev += (e >= o[l] - rel0) ? 1 : 0;
+    atomicAdd(&v.s_d[tl * v.levels + lev], 1u);
+    if (v.log_hits) {
+        const ScanRare r = *v.rare;
+        unsigned long long h = atomicAdd(r.hit_count, 1ull);
+        if ((long long)h < r.hit_cap)
+            r.hits[h] = wd_hit{v.tile, v.t_first + tl, rel0 + e, dist};
+    }
+}
+
+__device__ inline void q_wave_sync()
+{
+    // LDS traffic of one wave is processed in order; this only stops the compiler from
+    // moving queue reads above the pushes of other lanes
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// Drain a wave's queue: every entry has seen cycles [0, j0); rounds of 2, 4, 8 ... more
+// cycles, one lane per survivor, re-compacting after each round.  Whoever is still alive
+// after kFinishFrom cycles is almost certainly a true duplicate (a random neighbour gets
+// there with probability 4^-8): those are finished one entry at a time with one LANE PER
+// CYCLE - a single ballot + popcount adds up 64 cycles' mismatches, so a duplicate costs
+// ceil((L - 8) / 64) round trips instead of (L - 8) / 8.  qn is reset to 0.
+constexpr int kFinishFrom = 8;
+template <bool STRIDED, int MAXB = 8>
+__device__ inline void q_drain(const QEnv &v, uint2 *q_a, uint2 *q_b, int &qn, int j0, int lane)
+{
+    q_wave_sync();
+    const int L = v.L, k = v.k;
+    int j = min(j0, L);
+    int nb = 2;
+    uint2 *qa = q_a, *qb = q_b;
+    int n = qn;
+    while (n > 0 && j < L) {
+        if (j >= kFinishFrom) {
+            for (int i = 0; i < n; i++) {
+                const uint2 ent = qa[i];                       // same address in every lane
+                const uint32_t idx = ent.x;
+                const int tl = (int)(ent.y >> 24);
+                const uint32_t c = (uint32_t)v.s_centre[tl];
+                int mm = (int)((ent.y >> 16) & 0xFFu);
+                for (int j0 = j; j0 < L && mm <= k; j0 += kWave) {
+                    const int jj = j0 + lane;
+                    gbytes p = q_plane<STRIDED>(v, min(jj, L - 1));
+                    const bool diff = code_of(p[idx]) != code_of(p[c]);
+                    mm += __popcll(__ballot(jj < L && diff));
+                }
+                if (mm <= k && lane == 0)
+                    q_record_dup(v, tl, (int)(ent.y & 0xFFFFu), mm);
+            }
+            break;
+        }
+        const bool last = j + nb >= L;
+        int n2 = 0;
+        for (int p0 = 0; p0 < n; p0 += kWave) {
+            const bool have = p0 + lane < n;
+            uint2 ent = make_uint2(0u, 0u);
+            if (have)
+                ent = qa[p0 + lane];
+            const uint32_t idx = ent.x;
+            const int tl = (int)(ent.y >> 24);
+            const int e = (int)(ent.y & 0xFFFFu);
+            int mm = (int)((ent.y >> 16) & 0xFFu);
+            if (have) {
+                const uint32_t c = (uint32_t)v.s_centre[tl];
+                uint32_t w[MAXB], cb[MAXB];
+#pragma unroll
+                for (int q = 0; q < MAXB; q++) {
+                    if (q < nb) {
+                        gbytes p = q_plane<STRIDED>(v, min(j + q, L - 1));
+                        w[q] = p[idx];
+                        cb[q] = p[c];
+                    }
+                }
+#pragma unroll
+                for (int q = 0; q < MAXB; q++) {
+                    if (q < nb && j + q < L)
+                        mm += code_of(w[q]) != code_of(cb[q]) ? 1 : 0;
+                }
+            }
+            const bool alive = have && mm <= k;
+            if (last) {
+                if (alive)
+                    q_record_dup(v, tl, e, mm);
+            } else {
+                const uint64_t m = __ballot(alive);
+                if (alive) {
+                    const int pos = n2 + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32),
+                                             __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+                    qb[pos] = make_uint2(idx, (ent.y & 0xFF00FFFFu) | ((uint32_t)min(mm, 255) << 16));
+                }
+                n2 += __popcll(m);
+            }
+        }
+        q_wave_sync();
+        uint2 *t = qa; qa = qb; qb = t;
+        n = last ? 0 : n2;
+        j += nb;
+        nb = min(MAXB, nb * 2);
+    }
+    qn = 0;
+}
+
+// Push the lanes flagged `alive` (ballot m) behind the qn entries already queued.
+__device__ inline void q_push(uint2 *q_a, int qn, uint64_t m, bool alive, uint32_t idx, uint32_t tag)
+{
+    if (alive) {
+        const int pos = qn + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32),
+                                 __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+        q_a[pos] = make_uint2(idx, tag);
+    }
+}
+
 __host__ __device__ inline int scan_q_lds_dwords(int levels, int tpb)
 {
     int n = (1 + 5 * levels) + tpb + tpb * (levels + 1) + tpb * levels + tpb + kMaxPasses * tpb + 4;
@@ -638,86 +781,21 @@ __global__ __launch_bounds__(kBlock, 6) void k_scan_q(ScanArgs a)
     }
     __syncthreads();
 
-    // a duplicate found: bump its target's per-level counter (and the optional hit log)
-    auto record_dup = [&](int tl, int e, int dist) {
-        const int32_t *o = s_off + tl * (levels + 1);
-        const int rel0 = o[0];
-        int lev = 0;
-        for (int l = 1; l < levels; l++)
-            lev += (e >= o[l] - rel0) ? 1 : 0;
-        atomicAdd(&s_d[tl * levels + lev], 1u);
-        if (a.log_hits) {
-            const ScanRare r = *a.rare;
-            unsigned long long h = atomicAdd(r.hit_count, 1ull);
-            if ((long long)h < r.hit_cap)
-                r.hits[h] = wd_hit{tile, t_first + tl, rel0 + e, dist};
-        }
-    };
-
-    // ---------------- phase 2 (defined first: phase 1 calls it when the queue is full) ------
+    QEnv env;
+    env.s_centre = s_centre;
+    env.s_off = s_off;
+    env.s_d = s_d;
+    env.base0 = base0;
+    env.ptab = ptab;
+    env.stride = stride;
+    env.rare = a.rare;
+    env.levels = levels;
+    env.L = L;
+    env.k = k;
+    env.tile = tile;
+    env.t_first = t_first;
+    env.log_hits = a.log_hits;
     int qn = 0;
-    auto drain = [&]() {
-        // queue pushes by other lanes of this wave must be visible before the reads below
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        int j = min(B1, L);
-        int nb = 2;
-        uint2 *qa = q_a, *qb = q_b;
-        int n = qn;
-        while (n > 0 && j < L) {
-            const bool last = j + nb >= L;
-            int n2 = 0;
-            for (int p0 = 0; p0 < n; p0 += kWave) {
-                const bool have = p0 + lane < n;
-                uint2 ent = make_uint2(0u, 0u);
-                if (have)
-                    ent = qa[p0 + lane];
-                const uint32_t idx = ent.x;
-                const int tl = (int)(ent.y >> 24);
-                const int e = (int)(ent.y & 0xFFFFu);
-                int mm = (int)((ent.y >> 16) & 0xFFu);
-                if (have) {
-                    const uint32_t c = (uint32_t)s_centre[tl];
-                    uint32_t w[8], cb[8];
-#pragma unroll
-                    for (int q = 0; q < 8; q++) {
-                        if (q < nb) {
-                            gbytes p = plane_ptr(min(j + q, L - 1));
-                            w[q] = p[idx];
-                            cb[q] = p[c];
-                        }
-                    }
-#pragma unroll
-                    for (int q = 0; q < 8; q++) {
-                        if (q < nb && j + q < L)
-                            mm += code_of(w[q]) != code_of(cb[q]) ? 1 : 0;
-                    }
-                }
-                const bool alive = have && mm <= k;
-                if (last) {
-                    if (alive)
-                        record_dup(tl, e, mm);
-                } else {
-                    const uint64_t m = __ballot(alive);
-                    if (alive) {
-                        const int pos = n2 + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32),
-                                                 __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-                        qb[pos] = make_uint2(idx, (ent.y & 0xFF00FFFFu) | ((uint32_t)min(mm, 255) << 16));
-                    }
-                    n2 += __popcll(m);
-                }
-            }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            uint2 *t = qa; qa = qb; qb = t;
-            n = last ? 0 : n2;
-            j += nb;
-            nb = min(8, nb * 2);
-        }
-        qn = 0;
-    };
 
     // ---------------- phase 1: pipelined first round over this wave's items -----------------
     const int nitems = (int)s_misc[0];
@@ -795,33 +873,24 @@ __global__ __launch_bounds__(kBlock, 6) void k_scan_q(ScanArgs a)
                 if (m0 | m1) {
                     if (B1 >= L) {
                         if (al0)
-                            record_dup(tl, e0, mm0);
+                            q_record_dup(env, tl, e0, mm0);
                         if (al1)
-                            record_dup(tl, e1, mm1);
+                            q_record_dup(env, tl, e1, mm1);
                     } else {
                         const int n0 = __popcll(m0), n1 = __popcll(m1);
                         if (qn + n0 + n1 > kQCap)
-                            drain();
-                        if (al0) {
-                            const int pos = qn + __builtin_amdgcn_mbcnt_hi((uint32_t)(m0 >> 32),
-                                                     __builtin_amdgcn_mbcnt_lo((uint32_t)m0, 0u));
-                            q_a[pos] = make_uint2(i0_3, ((uint32_t)tl << 24) | ((uint32_t)min(mm0, 255) << 16) | (uint32_t)e0);
-                        }
-                        if (al1) {
-                            const int pos = qn + n0 + __builtin_amdgcn_mbcnt_hi((uint32_t)(m1 >> 32),
-                                                          __builtin_amdgcn_mbcnt_lo((uint32_t)m1, 0u));
-                            q_a[pos] = make_uint2(i1_3, ((uint32_t)tl << 24) | ((uint32_t)min(mm1, 255) << 16) | (uint32_t)e1);
-                        }
+                            q_drain<STRIDED>(env, q_a, q_b, qn, B1, lane);
+                        q_push(q_a, qn, m0, al0, i0_3,
+                               ((uint32_t)tl << 24) | ((uint32_t)min(mm0, 255) << 16) | (uint32_t)e0);
+                        q_push(q_a, qn + n0, m1, al1, i1_3,
+                               ((uint32_t)tl << 24) | ((uint32_t)min(mm1, 255) << 16) | (uint32_t)e1);
                         qn += n0 + n1;
                     }
                 }
             }
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         if (qn > 0)
-            drain();
+            q_drain<STRIDED>(env, q_a, q_b, qn, B1, lane);
     }
     __syncthreads();
 
@@ -863,6 +932,218 @@ __global__ __launch_bounds__(kBlock, 6) void k_scan_q(ScanArgs a)
     }
     if (lane == 0 && acc_valid)
         atomicAdd(&s_cnt[0], acc_valid);
+    __syncthreads();
+    for (int i = threadIdx.x; i < ncnt; i += kBlock) {
+        const uint32_t v = s_cnt[i];
+        if (v)
+            atomicAdd(&a.out_tile[(size_t)tile * ncnt + i], (unsigned long long)v);
+    }
+}
+
+// -------------------------------------------------------------------------------------
+// Dense kernel (Hamming family): one LANE per target - for "every well is a centre" scans
+// -------------------------------------------------------------------------------------
+// With millions of targets of ~36 neighbours each (BASELINE config 5) a wave per target wastes
+// most lanes and pays hundreds of instructions per target.  Here consecutive lanes own
+// consecutive centres: for the q-th neighbour the 64 lanes read 64 mostly consecutive wells,
+// so plane loads coalesce and the planes' first cycles are effectively streamed once through
+// L2, while each lane walks its own index list.  Round 1 reads 2 cycles of every neighbour;
+// survivors go through the same per-wave LDS queue and dense drain rounds as k_scan_q
+// (walking them lane by lane instead costs ~350 k cycles of dependent loads per wave).
+// Neighbour lists regrouped for the lane-per-target kernel: for each group of 64 consecutive
+// targets, nbr_t[gbase + q*64 + lane] is the q-th neighbour of target 64*group + lane (the
+// target's own centre where q >= K), so that one wave-load reads 256 contiguous bytes.
+__global__ __launch_bounds__(kWave) void k_transpose_nbr(const int32_t *centre, const int32_t *lvl_off,
+                                                         const int32_t *nbr, const long long *gbase,
+                                                         int32_t *nbr_t, int T, int levels)
+{
+    const int g = blockIdx.x;
+    const int lane = threadIdx.x;
+    const int t = g * kWave + lane;
+    const bool in = t < T;
+    const int off0 = in ? lvl_off[(size_t)t * (levels + 1)] : 0;
+    const int K = in ? lvl_off[(size_t)t * (levels + 1) + levels] - off0 : 0;
+    const int c = in ? centre[t] : 0;
+    const long long b0 = gbase[g], b1 = gbase[g + 1];
+    const int kmax = (int)((b1 - b0) / kWave);
+    for (int q = 0; q < kmax; q++)
+        nbr_t[b0 + (long long)q * kWave + lane] = q < K ? nbr[off0 + q] : c;
+}
+
+constexpr int kDenseMaxK = 16384;   // slot index must fit the queue tag's 16 bits
+constexpr int kDenseQCap = 256;
+
+__host__ __device__ inline int scan_dense_lds_dwords(int levels)
+{
+    int n = (1 + 5 * levels) + kBlock + kBlock * (levels + 1) + kBlock * levels;
+    n = (n + 1) & ~1;
+    return n + kWaves * 2 * kDenseQCap * 2;
+}
+
+template <bool STRIDED>
+__global__ __launch_bounds__(kBlock) void k_scan_dense(ScanArgs a)
+{
+    extern __shared__ uint32_t smem[];
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int levels = a.levels;
+    const int L = a.L;
+    const int k = a.k;
+    const int ncnt = 1 + 5 * levels;
+    const int bpt = (a.T + kBlock - 1) / kBlock;
+    const int tile = blockIdx.x / bpt;
+    const int t_first = (blockIdx.x - tile * bpt) * kBlock;
+    const int tl = threadIdx.x;
+    const int t = t_first + tl;
+    const bool in = t < a.T;
+
+    uint32_t *s_cnt = smem;
+    int32_t *s_centre = (int32_t *)(s_cnt + ncnt);
+    int32_t *s_off = s_centre + kBlock;
+    uint32_t *s_d = (uint32_t *)(s_off + kBlock * (levels + 1));
+    const int q_base = (int)((((s_d + kBlock * levels) - smem) + 1) & ~1);
+    uint2 *q_a = (uint2 *)(smem + q_base) + wave * 2 * kDenseQCap;
+    uint2 *q_b = q_a + kDenseQCap;
+
+    gbytes filt = as_global(a.filter[tile]);
+    const uint8_t *const *ptab = STRIDED ? nullptr : a.planes + (size_t)tile * L;
+    gbytes base0 = STRIDED ? as_global(a.planes[tile]) : nullptr;
+    const int64_t stride = a.stride;
+    auto plane_ptr = [&](int j) -> gbytes {
+        return STRIDED ? base0 + (int64_t)j * stride : as_global(ptab[j]);
+    };
+
+    // ---- phase 0: this lane's target ----
+    for (int i = threadIdx.x; i < ncnt; i += kBlock)
+        s_cnt[i] = 0;
+    for (int l = 0; l < levels; l++)
+        s_d[tl * levels + l] = 0;
+    const int32_t *off = a.lvl_off + (size_t)(in ? t : 0) * (levels + 1);
+    const uint32_t c = in ? (uint32_t)a.centre[t] : 0u;
+    s_centre[tl] = (int32_t)c;
+    for (int l = 0; l <= levels; l++)
+        s_off[tl * (levels + 1) + l] = off[l];
+    bool valid = in && ((uint32_t)filt[c] & 1u);                       // :236-237
+    if (a.check_empty && valid) {                                      // :249
+        bool empty = false;
+        for (int l = 0; l < levels; l++)
+            empty = empty || (off[l + 1] <= off[l]);
+        if (empty) {
+            atomicOr(a.rare->status, kStatusEmptyLevel);
+            valid = false;
+        }
+    }
+    const int off0 = off[0];
+    const int K = valid ? off[levels] - off0 : 0;
+    __syncthreads();
+
+    QEnv env;
+    env.s_centre = s_centre;
+    env.s_off = s_off;
+    env.s_d = s_d;
+    env.base0 = base0;
+    env.ptab = ptab;
+    env.stride = stride;
+    env.rare = a.rare;
+    env.levels = levels;
+    env.L = L;
+    env.k = k;
+    env.tile = tile;
+    env.t_first = t_first;
+    env.log_hits = a.log_hits;
+    int qn = 0;
+
+    // ---- phase 1: cycles 0 and 1 of every neighbour, one lane per target ----
+    gbytes p0 = plane_ptr(0);
+    gbytes p1 = plane_ptr(min(1, L - 1));
+    const uint32_t cc0 = code_of(p0[c]);
+    const uint32_t cc1 = code_of(p1[c]);
+    int kmax = K;                                     // wave-wide trip count
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1)
+        kmax = max(kmax, __shfl_xor(kmax, d));
+    // this wave's group of 64 targets in the transposed neighbour table
+    const long long gb = a.gbase[(t_first >> 6) + wave];
+    const int gk = (int)((a.gbase[(t_first >> 6) + wave + 1] - gb) >> 6);     // >= kmax
+    const int32_t *nt = a.nbr_t + gb + lane;
+#ifndef WD_DENSE_U
+#define WD_DENSE_U 4
+#endif
+#ifndef WD_DENSE_MAXB
+#define WD_DENSE_MAXB 8
+#endif
+    constexpr int U = WD_DENSE_U;                      // neighbours per step
+    uint32_t idx[U], nxt[U];
+#pragma unroll
+    for (int u = 0; u < U; u++)
+        idx[u] = (uint32_t)nt[(size_t)min(u, gk - 1) * kWave];           // own centre where q >= K
+    for (int q0 = 0; q0 < kmax; q0 += U) {
+        uint32_t w0[U], w1[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {                  // next step's indices ride behind
+            nxt[u] = (uint32_t)nt[(size_t)min(q0 + U + u, gk - 1) * kWave];
+            w0[u] = p0[idx[u]];
+            w1[u] = p1[idx[u]];
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const int mm = (code_of(w0[u]) != cc0 ? 1 : 0) + ((L > 1 && code_of(w1[u]) != cc1) ? 1 : 0);
+            const bool alive = q0 + u < K && mm <= k;
+            const uint64_t m = __ballot(alive);
+            if (m) {
+                if (L <= 2) {
+                    if (alive)
+                        q_record_dup(env, tl, q0 + u, mm);
+                } else {
+                    const int n = __popcll(m);
+                    if (qn + n > kDenseQCap)
+                        q_drain<STRIDED, WD_DENSE_MAXB>(env, q_a, q_b, qn, 2, lane);
+                    q_push(q_a, qn, m, alive, idx[u],
+                           ((uint32_t)tl << 24) | ((uint32_t)mm << 16) | (uint32_t)(q0 + u));
+                    qn += n;
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++)
+            idx[u] = nxt[u];
+    }
+    // ---- phase 2: survivors, dense lanes ----
+    if (qn > 0)
+        q_drain<STRIDED, WD_DENSE_MAXB>(env, q_a, q_b, qn, 2, lane);
+    __syncthreads();
+
+    // ---- phase 3: tallies, one lane per target ----
+    uint32_t hm = 0;
+    for (int l = 0; l < levels; l++)
+        hm |= (valid && s_d[tl * levels + l]) ? (1u << l) : 0u;
+    const uint64_t vmask = __ballot(valid);
+    if (lane == 0 && vmask)
+        atomicAdd(&s_cnt[0], (uint32_t)__popcll(vmask));
+    for (int l = 0; l < levels; l++) {
+        int w = valid ? off[l + 1] - off[l] : 0;
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1)
+            w += __shfl_xor(w, d);
+        if (lane == 0 && w)
+            atomicAdd(&s_cnt[1 + l], (uint32_t)w);
+    }
+    if (hm) {
+        for (int l = 0; l < levels; l++) {
+            const uint32_t d = s_d[tl * levels + l];
+            if (d) {
+                atomicAdd(&s_cnt[1 + levels + l], d);
+                atomicAdd(&s_cnt[1 + 2 * levels + l], 1u);
+            }
+        }
+        atomicAdd(&s_cnt[1 + 3 * levels + (__ffs((int)hm) - 1)], 1u);
+        atomicAdd(&s_cnt[1 + 4 * levels + (31 - __clz((int)hm))], 1u);
+    }
+    if (a.out_per_target && in) {
+        uint32_t *opt = a.out_per_target + ((size_t)tile * a.T + t) * levels;
+        for (int l = 0; l < levels; l++)
+            opt[l] = valid ? s_d[tl * levels + l] : WD_INVALID_TARGET;
+    }
     __syncthreads();
     for (int i = threadIdx.x; i < ncnt; i += kBlock) {
         const uint32_t v = s_cnt[i];
@@ -1148,6 +1429,7 @@ struct wd_ctx {
     int batch_next = 4;
     int queue_kernel = 1;      // equality / Hamming with early exit: use k_scan_q
     int queue_first = 0;       // cycles of its first round; 0 = choose from k
+    int dense_kernel = -1;     // lane-per-target kernel: -1 = when the targets look dense
     int profile = 0;
 
     // targets (device)
@@ -1156,6 +1438,9 @@ struct wd_ctx {
     int32_t *d_centre = nullptr, *d_lvl_off = nullptr, *d_nbr = nullptr;
     int64_t idx_min = 0, idx_max = -1;
     int64_t k_max = 0;         // most neighbour slots of any target
+    std::vector<long long> h_gbase;   // per 64-target group: start in the transposed table
+    int32_t *d_nbr_t = nullptr;       // built on first use of the dense kernel
+    long long *d_gbase = nullptr;
     bool has_targets = false;
     bool has_empty_level = false;
 
@@ -1297,6 +1582,46 @@ int launch_queue(wd_ctx *ctx, const ScanArgs &a, dim3 grid)
     return 0;
 }
 
+// Group bases of the transposed neighbour table from host-side ring offsets (row = levels+1).
+void set_group_bases(wd_ctx *ctx, const int32_t *lvl_off, int T, int levels)
+{
+    const size_t row = (size_t)levels + 1;
+    const int groups = (T + kWave - 1) / kWave;
+    ctx->h_gbase.assign((size_t)groups + 1, 0);
+    long long pos = 0;
+    for (int g = 0; g < groups; g++) {
+        int kmax = 1;                                  // at least one row so min(q, gk-1) is valid
+        for (int t = g * kWave; t < std::min(T, (g + 1) * kWave); t++)
+            kmax = std::max(kmax, lvl_off[(size_t)t * row + levels] - lvl_off[(size_t)t * row]);
+        ctx->h_gbase[g] = pos;
+        pos += (long long)kmax * kWave;
+    }
+    ctx->h_gbase[groups] = pos;
+    (void)hipFree(ctx->d_nbr_t);
+    (void)hipFree(ctx->d_gbase);
+    ctx->d_nbr_t = nullptr;
+    ctx->d_gbase = nullptr;
+}
+
+// Build the device copy of the transposed table (first dense scan after new targets).
+int ensure_dense_tables(wd_ctx *ctx)
+{
+    if (ctx->d_nbr_t)
+        return WD_OK;
+    const int groups = (ctx->T + kWave - 1) / kWave;
+    const long long total = ctx->h_gbase.empty() ? 0 : ctx->h_gbase.back();
+    WD_HIP(ctx, hipMalloc((void **)&ctx->d_gbase, (size_t)(groups + 1) * sizeof(long long)));
+    WD_HIP(ctx, hipMalloc((void **)&ctx->d_nbr_t, std::max<long long>(1, total) * sizeof(int32_t)));
+    WD_HIP(ctx, hipMemcpyAsync(ctx->d_gbase, ctx->h_gbase.data(), (size_t)(groups + 1) * sizeof(long long),
+                               hipMemcpyHostToDevice, ctx->stream));
+    if (groups > 0)
+        hipLaunchKernelGGL(k_transpose_nbr, dim3(groups), dim3(kWave), 0, ctx->stream, ctx->d_centre,
+                           ctx->d_lvl_off, ctx->d_nbr, ctx->d_gbase, ctx->d_nbr_t, ctx->T, ctx->levels);
+    WD_HIP(ctx, hipGetLastError());
+    WD_HIP(ctx, hipStreamSynchronize(ctx->stream));       // h_gbase may be reused by the caller
+    return WD_OK;
+}
+
 bool valid_batches(int b1, int b2)
 {
     for (auto &p : kHamShapes)
@@ -1390,6 +1715,8 @@ void wd_destroy(wd_ctx *ctx)
     (void)hipFree(ctx->d_tbl);
     (void)hipFree(ctx->d_status);
     (void)hipFree(ctx->d_rare);
+    (void)hipFree(ctx->d_nbr_t);
+    (void)hipFree(ctx->d_gbase);
     (void)hipHostFree(ctx->h_status);
     (void)hipFree(ctx->d_out_tile);
     (void)hipFree(ctx->d_out_pt);
@@ -1445,6 +1772,8 @@ int wd_set_option(wd_ctx *ctx, const char *name, int64_t value)
             return WD_ERR_HIP;
         WD_HIP(ctx, hipStreamSynchronize(ctx->stream));
         ctx->stream = value ? (hipStream_t) nullptr : ctx->own_stream;
+    } else if (n == "dense_kernel") {
+        ctx->dense_kernel = value < 0 ? -1 : (value ? 1 : 0);
     } else if (n == "queue_kernel") {
         ctx->queue_kernel = value ? 1 : 0;
     } else if (n == "queue_first") {
@@ -1468,6 +1797,7 @@ int wd_get_option(wd_ctx *ctx, const char *name, int64_t *value)
     else if (n == "batch_next") *value = ctx->batch_next;
     else if (n == "profile") *value = ctx->profile;
     else if (n == "queue_kernel") *value = ctx->queue_kernel;
+    else if (n == "dense_kernel") *value = ctx->dense_kernel;
     else if (n == "null_stream") *value = ctx->stream == nullptr ? 1 : 0;
     else if (n == "queue_first") *value = ctx->queue_first;
     else return fail(ctx, WD_ERR_ARG, "unknown option " + n);
@@ -1589,6 +1919,7 @@ int wd_set_targets(wd_ctx *ctx, int T, int levels, const int32_t *centre, const 
     ctx->k_max = 0;
     for (int t = 0; t < T; t++)
         ctx->k_max = std::max<int64_t>(ctx->k_max, (int64_t)lvl_off[(size_t)t * row + levels] - lvl_off[(size_t)t * row]);
+    set_group_bases(ctx, lvl_off, T, levels);
     ctx->has_targets = true;
     return WD_OK;
 }
@@ -1692,6 +2023,8 @@ int wd_scan_async(wd_ctx *ctx, int n_tiles, int L, int mode, int k, const uint8_
         }
     }
     a.rare = ctx->d_rare;
+    a.nbr_t = nullptr;
+    a.gbase = nullptr;
     a.log_hits = ctx->hit_cap > 0 ? 1 : 0;
     a.T = ctx->T;
     a.levels = levels;
@@ -1703,8 +2036,16 @@ int wd_scan_async(wd_ctx *ctx, int n_tiles, int L, int mode, int k, const uint8_
     if (ctx->hit_cap > 0)
         WD_HIP(ctx, hipMemsetAsync(ctx->d_hit_count, 0, sizeof(unsigned long long), ctx->stream));
 
+    // lane-per-target kernel: many small targets (every well a centre), Hamming family
+    const bool dense_ok = !lev && ctx->early_exit && L >= 1 && ctx->k_max <= kDenseMaxK &&
+                          levels <= 8 && kk <= 2 && kk >= 0;      // levels: LDS budget (35 KB)
+    // (with k >= 2 nothing can die within the 2-cycle first round, so only on request)
+    const bool use_dense = dense_ok && (ctx->dense_kernel == 1 ||
+                                        (ctx->dense_kernel < 0 && ctx->T >= 65536 && kk <= 1));
     const int chunks = (ctx->T + ctx->tpb - 1) / ctx->tpb;
-    const long long nblocks = lev_generic ? (long long)ctx->T * n_tiles : (long long)chunks * n_tiles;
+    const long long nblocks = lev_generic ? (long long)ctx->T * n_tiles
+                              : use_dense ? (long long)((ctx->T + kBlock - 1) / kBlock) * n_tiles
+                                          : (long long)chunks * n_tiles;
     if (nblocks > 0x7FFFFFFFll)
         return fail(ctx, WD_ERR_UNSUPPORTED, "grid too large; raise targets_per_block");
     dim3 grid((unsigned)nblocks);
@@ -1722,7 +2063,18 @@ int wd_scan_async(wd_ctx *ctx, int n_tiles, int L, int mode, int k, const uint8_
     }
     const bool use_queue = !lev && ctx->queue_kernel && ctx->early_exit && kk <= 254 &&
                            ctx->k_max <= (int64_t)kMaxPasses * kPass;
-    if (use_queue) {
+    if (use_dense) {
+        int rc = ensure_dense_tables(ctx);
+        if (rc)
+            return rc;
+        a.nbr_t = ctx->d_nbr_t;
+        a.gbase = ctx->d_gbase;
+        const size_t lds = (size_t)scan_dense_lds_dwords(levels) * sizeof(uint32_t);
+        if (strided)
+            hipLaunchKernelGGL((k_scan_dense<true>), grid, dim3(kBlock), lds, ctx->stream, a);
+        else
+            hipLaunchKernelGGL((k_scan_dense<false>), grid, dim3(kBlock), lds, ctx->stream, a);
+    } else if (use_queue) {
         if (strided)
             launch_queue<true>(ctx, a, grid);
         else
@@ -1995,6 +2347,7 @@ int wd_targets_from_coords(wd_ctx *ctx, const int32_t *x, const int32_t *y, int6
     for (int t = 0; t < T; t++)
         ctx->k_max = std::max<int64_t>(ctx->k_max, (int64_t)off[(size_t)t * (levels + 1) + levels] -
                                                         off[(size_t)t * (levels + 1)]);
+    set_group_bases(ctx, off.data(), T, levels);
     ctx->has_targets = true;
     if (P_out)
         *P_out = P;
