@@ -15,6 +15,7 @@ ap.add_argument("--bases", type=int, default=150)
 ap.add_argument("--tiles", type=int, default=2)
 ap.add_argument("--mode", type=int, default=0)
 ap.add_argument("-k", type=int, default=0)
+ap.add_argument("--plant", type=int, default=1311, help="planted wells per 65536 (1311 = 2 %%)")
 a = ap.parse_args()
 n = a.rows * a.cols
 x, y = synth.honeycomb_pixels(a.rows, a.cols)
@@ -22,7 +23,7 @@ sc = Scanner(0)
 t0 = time.time()
 T, P = sc.targets_from_coords(x, y, None, levels=a.levels)
 print("generator: %d centres, %d slots (%.1f per centre) in %.2f s" % (T, P, P / T, time.time() - t0))
-spec = synth.SynthSpec(seed=5, n_clusters=n, row=a.cols)
+spec = synth.SynthSpec(seed=5, n_clusters=n, row=a.cols, plant_per_64k=a.plant)
 tb = TileBatch(sc, a.tiles, a.bases, n)
 tb.fill_synthetic(spec, [(1, 1101 + i) for i in range(a.tiles)], list(range(a.bases)))
 out = sc.malloc(a.tiles * (1 + 5 * a.levels) * 8)
