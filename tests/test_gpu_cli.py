@@ -66,3 +66,27 @@ def test_cli_tile_batching_and_errors(tmp_path_factory):
     with pytest.raises(RuntimeError):                     # tile without files (bcl :131-132)
         cwd.main(["-f", os.path.join(GOLD, fx["targets_file"]), "-s", "hiseq_4000", "-r", run_dir,
                   "-t", "1103", "-i", "1", "-q", "--cycles", "0-50", "-l", "5"])
+
+
+def test_cli_two_ranks_one_gpu(tmp_path_factory, tmp_path):
+    """torchrun with 2 ranks (both on GPU 0, gloo for the collective): tiles are sharded, the
+    merged report and duplicate log equal the reference's single-process output."""
+    import subprocess
+    import sys
+    fx, run_dir = _run_dir(tmp_path_factory, "far")
+    run = fx["runs"][2]                                   # Levenshtein <= 2, 3 tiles
+    argv = ["-f", os.path.join(GOLD, fx["targets_file"]), "-n", str(fx["n_targets"]),
+            "-l", str(fx["levels"]), "-s", fx.get("stype", "hiseq_4000"), "-r", run_dir,
+            "-t", ",".join(fx["tiles"]), "-i", ",".join(str(l) for l in fx["lanes"])]
+    argv += run["flags"] + ["--device", "0", "--dist-backend", "gloo"]
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                          "--master-addr", "127.0.0.1", "--master-port", "29541",
+                          "-m", "well_duplicates_amd.count_well_duplicates"] + argv,
+                         cwd=repo, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert res.returncode == 0, res.stderr.decode()[-2000:]
+    out = "".join(ln for ln in res.stdout.decode().splitlines(True) if not ln.startswith("[Gloo]"))
+    assert out == run["stdout"]          # (gloo prints a connection banner on stdout)
+    keep = ("center seq at", "well seq at", "edit distance:")
+    log = [ln for ln in res.stderr.decode().splitlines() if ln.startswith(keep)]
+    assert log == run["dup_log"]

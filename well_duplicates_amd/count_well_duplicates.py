@@ -10,6 +10,11 @@ Flow per lane (the reference's unit of output, :207-269):
 Unless -q is given the stderr log is reproduced too, including the three lines the
 reference prints per duplicate (:258-262), from the device's hit list.
 
+Multi-GPU: started under torchrun (one process per GPU) the tiles of every lane are
+block-partitioned over the ranks, each rank scans its share on its own GPU, one int64
+all-reduce merges the per-tile counter rows (well_duplicates_amd/dist.py) and rank 0 prints
+the report - identical to the single-GPU output.
+
 Differences from the reference, all deliberate:
   * a lane with valid targets but no duplicate prints 0.00 % instead of dying with
     ZeroDivisionError (F5); --strict restores the exception;
@@ -77,7 +82,10 @@ def parse_args(argv=None):
                    help="Only print the summary per lane, not for every tile")
     p.add_argument("-q", "--quiet", action="store_true", help="No log output")
     p.add_argument("--version", action="version", version=str(__VERSION__))
-    p.add_argument("--device", type=int, default=0, help="GPU to run on")
+    p.add_argument("--device", type=int, default=None,
+                   help="GPU to run on (default: LOCAL_RANK under torchrun, else 0)")
+    p.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
+                   help="collective backend under torchrun (nccl = RCCL; gloo = CPU, for rehearsals)")
     p.add_argument("--tile-batch", type=int, default=32,
                    help="tiles kept resident in HBM and scanned per launch")
     p.add_argument("--threads", type=int, default=min(16, os.cpu_count() or 1),
@@ -170,17 +178,49 @@ def main(argv=None):
     wells = np.unique(np.asarray(targets.get_all_indices(), dtype=np.int64))
     reader = bcl_direct_reader.BCLReader(args.run)
 
-    with Scanner(args.device) as sc:
-        sc.set_targets(*csr)
-        for lane in lanes:
-            counts, logs = scan_lane(sc, reader, lane, tiles, cycle_list, mode, k, csr, wells,
-                                     max(1, args.tile_batch), args.threads,
-                                     0 if args.quiet else len(cycles))
-            for t in tiles:
-                for line in logs.get(t, ()):
-                    log(line)
-            report.write_report(lane, len(targets), counts, verbose=not args.summary_only,
-                                strict=args.strict)
+    from . import dist as wdist
+    rank, world, local_rank = wdist.env_rank()
+    device = args.device if args.device is not None else (local_rank if world > 1 else 0)
+    if world > 1:
+        import torch
+        import torch.distributed as tdist
+        if args.dist_backend == "nccl":
+            torch.cuda.set_device(device)
+            tdist.init_process_group("nccl", device_id=torch.device("cuda", device))
+        else:
+            tdist.init_process_group("gloo")
+    levels = args.level
+    try:
+        with Scanner(device) as sc:
+            sc.set_targets(*csr)
+            for lane in lanes:
+                mine = wdist.shard(tiles, rank, world)
+                counts, logs = scan_lane(sc, reader, lane, mine, cycle_list, mode, k, csr, wells,
+                                         max(1, args.tile_batch), args.threads,
+                                         0 if args.quiet else len(cycles))
+                if world > 1:
+                    import torch
+                    import torch.distributed as tdist
+                    rows = np.array([[counts[t].targets] + counts[t].wells + counts[t].dups + counts[t].hit
+                                     + counts[t].first + counts[t].last for t in mine],
+                                    dtype=np.int64).reshape(len(mine), 1 + 5 * levels)
+                    dev = torch.device("cuda", device) if args.dist_backend == "nccl" else torch.device("cpu")
+                    full = wdist.merge_blocks(torch.from_numpy(rows).to(dev), len(tiles), rank, world,
+                                              device=dev).cpu().numpy()
+                    counts = {t: report.TileCounts.from_block(full[i], levels) for i, t in enumerate(tiles)}
+                    gathered = [None] * world
+                    tdist.all_gather_object(gathered, logs)
+                    logs = {t: lines for part in gathered for t, lines in part.items()}
+                if rank == 0:
+                    for t in tiles:
+                        for line in logs.get(t, ()):
+                            log(line)
+                    report.write_report(lane, len(targets), counts, verbose=not args.summary_only,
+                                        strict=args.strict)
+    finally:
+        if world > 1:
+            import torch.distributed as tdist
+            tdist.destroy_process_group()
     return 0
 
 
