@@ -20,6 +20,8 @@
  *       WD_ERR_EMPTY_LEVEL  -> AssertionError   (count_well_duplicates.py:249)
  *       WD_ERR_ARG          -> ValueError
  *       WD_ERR_NO_WELLS     -> RuntimeError     (prepare_cluster_indexes.py:70-76)
+ *       WD_ERR_IO           -> FileNotFoundError / OSError (bcl_direct_reader.py:207-216)
+ *       WD_ERR_FORMAT       -> AssertionError   (bcl_direct_reader.py:151, :236, :338)
  *       everything else     -> RuntimeError
  */
 #ifndef WELLDUP_H
@@ -42,6 +44,8 @@ extern "C" {
 #define WD_ERR_UNSUPPORTED (-7)
 #define WD_ERR_COMM (-8)
 #define WD_ERR_NO_WELLS (-9)
+#define WD_ERR_IO (-10)
+#define WD_ERR_FORMAT (-11)
 
 /* Compare modes.  The reference counts a duplicate when dist <= edit_distance
  * (count_well_duplicates.py:258) with dist = Levenshtein.distance, or Levenshtein.hamming
@@ -166,6 +170,22 @@ int wd_scan_async(wd_ctx *ctx, int n_tiles, int L, int mode, int k,
                   const uint8_t *const *planes, const uint8_t *const *filter, int64_t N,
                   int64_t *out_tile_dev, uint32_t *out_per_target_dev);
 int wd_scan_status(wd_ctx *ctx);
+
+/*
+ * Ingest: files of a run directory straight into device memory, replacing the file side of
+ * Tile.get_seqs / _get_filter_offsets / _get_seqs_from_bcl (bcl_direct_reader.py:200-216,
+ * :232-240, :333-345).  wd_load_bcl_gz gunzips `<cycle dir>/<tile>.bcl.gz` (zlib) into a pinned
+ * staging buffer, checks the uint32 cluster count (:338) and copies the n_clusters payload bytes
+ * to dst_dev; wd_load_filter does the same for a .filter file (header 0, 3, n: :148-152).
+ * Both are THREAD-SAFE on one context (each call leases its own staging buffer and copy
+ * stream): call them from a pool of host threads so that gunzip, PCIe and the GPU overlap.
+ * wd_gather_wells returns out[w*L + c] = planes[c][idx[w]] (host output): the bytes of the
+ * wells the stderr duplicate log prints, without a host copy of the planes.
+ */
+int wd_load_bcl_gz(wd_ctx *ctx, const char *path, uint8_t *dst_dev, int64_t n_clusters);
+int wd_load_filter(wd_ctx *ctx, const char *path, uint8_t *dst_dev, int64_t n_clusters);
+int wd_gather_wells(wd_ctx *ctx, const uint8_t *const *planes, int L, const int32_t *idx, int64_t n,
+                    int64_t n_clusters, uint8_t *out_host);
 
 /*
  * Duplicate log: the (centre, well, distance) records the reference prints to stderr for

@@ -19,7 +19,7 @@ LIB_PATH = os.environ.get("WELLDUP_LIB") or os.path.join(HERE, "libwelldup.so")
 
 OK = 0
 ERR_ARG, ERR_INDEX, ERR_EMPTY_LEVEL, ERR_HIP, ERR_NOMEM, ERR_STATE, ERR_UNSUPPORTED, ERR_COMM, \
-    ERR_NO_WELLS = -1, -2, -3, -4, -5, -6, -7, -8, -9
+    ERR_NO_WELLS, ERR_IO, ERR_FORMAT = -1, -2, -3, -4, -5, -6, -7, -8, -9, -10, -11
 MODE_EQ, MODE_HAMMING, MODE_LEVENSHTEIN = 0, 1, 2
 MAX_LEVELS = 32
 INVALID_TARGET = 0xFFFFFFFF
@@ -68,6 +68,9 @@ PROTOTYPES = {
     "wd_count_tiles": (_i, [_vp, _i, _i, _i, _i, _pp, _pp, _i64, _vp, _vp]),
     "wd_scan_async": (_i, [_vp, _i, _i, _i, _i, _pp, _pp, _i64, _vp, _vp]),
     "wd_scan_status": (_i, [_vp]),
+    "wd_load_bcl_gz": (_i, [_vp, ctypes.c_char_p, _vp, _i64]),
+    "wd_load_filter": (_i, [_vp, ctypes.c_char_p, _vp, _i64]),
+    "wd_gather_wells": (_i, [_vp, _pp, _i, _vp, _i64, _i64, _vp]),
     "wd_hitlog_enable": (_i, [_vp, _i64]),
     "wd_hitlog_fetch": (_i, [_vp, _vp, _i64, ctypes.POINTER(_i64)]),
     "wd_profile_get": (_i, [_vp, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(_i64)]),
@@ -92,7 +95,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
             return LIB_PATH
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     cmd = [hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-shared",
-           "-I" + INCLUDE, "-o", LIB_PATH, SRC]
+           "-I" + INCLUDE, "-o", LIB_PATH, SRC, "-lz"]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)

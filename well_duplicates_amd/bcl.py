@@ -102,6 +102,10 @@ class Tile:
         return self._pass_index
 
     # ------------------------------------------------------------------ planes
+    def plane_path(self, cycle: int) -> str:
+        """Path of the .bcl.gz of 0-based `cycle` (it may not exist: NovaSeq runs have .cbcl)."""
+        return os.path.join(self.data_dir, "C%i.1" % (cycle + 1), self.bcl_filename)
+
     def read_plane(self, cycle: int) -> np.ndarray:
         """N base-call bytes of 0-based `cycle` (directory C<cycle+1>.1, :201)."""
         cycle_dir = os.path.join(self.data_dir, "C%i.1" % (cycle + 1))

@@ -119,17 +119,31 @@ def scan_lane(sc: Scanner, reader, lane, tiles, cycle_list, mode, k, csr, wells,
         tb = TileBatch(sc, len(chunk), len(cycle_list), n_clusters)
         seq_bytes = {}
         try:
+            if wells.size and (wells[-1] >= n_clusters or wells[0] < 0):
+                raise IndexError("Requested cluster %i is out of range.  Highest on this "
+                                 "tile is %i." % (int(wells[-1]), n_clusters - 1))
+
+            # ingest: every (tile, cycle) file is gunzipped into pinned memory and copied to
+            # the GPU by libwelldup (wd_load_bcl_gz; the ctypes call releases the GIL, so the
+            # pool's threads overlap gunzip, PCIe and each other).  Runs without .bcl.gz files
+            # (NovaSeq .cbcl) fall back to the Python reader + a plain upload.
+            def load(job):
+                i, c = job
+                try:
+                    sc.load_bcl_gz(handles[i].plane_path(cycle_list[c]), tb.plane_ptr(i, c), n_clusters)
+                    return None
+                except FileNotFoundError:
+                    return handles[i].read_plane(cycle_list[c])
+            jobs = [(i, c) for i in range(len(handles)) for c in range(len(cycle_list))]
+            for (i, c), plane in zip(jobs, pool.map(load, jobs)):
+                if plane is not None:
+                    sc.h2d(tb.plane_ptr(i, c), plane)
             for i, h in enumerate(handles):
-                planes = list(pool.map(h.read_plane, cycle_list))
-                filt = h.read_filter()
-                tb.upload_tile(i, planes, filt)
+                sc.load_filter(h.filter_file, tb.filter_ptr(i), n_clusters)
                 if want_log and wells.size:
-                    # keep only the bytes of wells some target touches, for the stderr log
-                    if wells[-1] >= n_clusters or wells[0] < 0:
-                        raise IndexError("Requested cluster %i is out of range.  Highest on this "
-                                         "tile is %i." % (int(wells[-1]), n_clusters - 1))
-                    seq_bytes[i] = np.stack([p[wells] for p in planes], axis=1) if planes else \
-                        np.zeros((wells.size, 0), np.uint8)
+                    # only the bytes of wells some target touches come back, for the stderr log
+                    seq_bytes[i] = sc.gather_wells([tb.plane_ptr(i, c) for c in range(len(cycle_list))],
+                                                   wells, n_clusters)
             if want_log:
                 sc.hitlog_enable(max(1024, int(nbr.size) * len(chunk)))
             blocks, _ = tb.count(mode, k)

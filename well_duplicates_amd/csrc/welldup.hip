@@ -22,12 +22,14 @@
 #include <hip/hip_runtime.h>
 
 #include <dlfcn.h>
+#include <zlib.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -1367,6 +1369,22 @@ __global__ __launch_bounds__(kBlock) void k_gen_rings(GenArgs a)
 }
 
 // -------------------------------------------------------------------------------------
+// Ingest helpers
+// -------------------------------------------------------------------------------------
+// out[w * L + c] = plane_c[idx[w]]: the bytes of a few wells over all scanned cycles (what the
+// stderr duplicate log prints), so whole planes never have to exist in host memory.
+__global__ __launch_bounds__(kBlock) void k_gather_wells(const uint8_t *const *planes, int L,
+                                                         const int32_t *idx, long long n, uint8_t *out)
+{
+    const long long i = (long long)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n * L)
+        return;
+    const long long w = i / L;
+    const int c = (int)(i - w * L);
+    out[i] = as_global(planes[c])[(uint32_t)idx[w]];
+}
+
+// -------------------------------------------------------------------------------------
 // RCCL, bound at run time
 // -------------------------------------------------------------------------------------
 struct Id128 { char b[WD_UNIQUE_ID_BYTES]; };   // ncclUniqueId, passed by value
@@ -1472,6 +1490,16 @@ struct wd_ctx {
 
     // comm
     void *comm = nullptr;
+
+    // ingest: pinned staging buffers + copy streams, one per concurrently loading thread
+    struct IngestSlot {
+        uint8_t *pinned = nullptr;
+        size_t cap = 0;
+        hipStream_t stream = nullptr;
+        bool busy = false;
+    };
+    std::mutex ingest_mu;
+    std::vector<IngestSlot *> ingest_slots;
 };
 
 namespace {
@@ -1652,6 +1680,8 @@ const char *wd_strerror(int code)
     case WD_ERR_UNSUPPORTED: return "unsupported parameter combination";
     case WD_ERR_COMM: return "RCCL error";
     case WD_ERR_NO_WELLS: return "a cluster has no wells at some level";
+    case WD_ERR_IO: return "cannot read file";
+    case WD_ERR_FORMAT: return "file header does not match the tile";
     default: return "unknown error";
     }
 }
@@ -1722,6 +1752,12 @@ void wd_destroy(wd_ctx *ctx)
     (void)hipFree(ctx->d_out_pt);
     (void)hipFree(ctx->d_hits);
     (void)hipFree(ctx->d_hit_count);
+    for (auto *sl : ctx->ingest_slots) {
+        (void)hipHostFree(sl->pinned);
+        if (sl->stream)
+            (void)hipStreamDestroy(sl->stream);
+        delete sl;
+    }
     if (ctx->own_stream)
         (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
@@ -2382,6 +2418,200 @@ int wd_get_targets(wd_ctx *ctx, int32_t *centre, int32_t *lvl_off, int32_t *nbr)
     if (nbr && ctx->P)
         WD_HIP(ctx, hipMemcpy(nbr, ctx->d_nbr, (size_t)ctx->P * 4, hipMemcpyDeviceToHost));
     return WD_OK;
+}
+
+// ---- ingest ---------------------------------------------------------------------------
+namespace {
+
+struct SlotLease {
+    wd_ctx *ctx;
+    wd_ctx::IngestSlot *slot = nullptr;
+    explicit SlotLease(wd_ctx *c) : ctx(c)
+    {
+        std::lock_guard<std::mutex> g(ctx->ingest_mu);
+        for (auto *s : ctx->ingest_slots)
+            if (!s->busy) {
+                slot = s;
+                break;
+            }
+        if (!slot) {
+            slot = new wd_ctx::IngestSlot();
+            ctx->ingest_slots.push_back(slot);
+        }
+        slot->busy = true;
+    }
+    ~SlotLease()
+    {
+        std::lock_guard<std::mutex> g(ctx->ingest_mu);
+        slot->busy = false;
+    }
+};
+
+// whole file -> memory; false if it cannot be opened / read
+bool slurp(const char *path, std::vector<uint8_t> &buf)
+{
+    FILE *f = fopen(path, "rb");
+    if (!f)
+        return false;
+    bool ok = fseek(f, 0, SEEK_END) == 0;
+    long n = ok ? ftell(f) : -1;
+    ok = ok && n >= 0 && fseek(f, 0, SEEK_SET) == 0;
+    if (ok) {
+        buf.resize((size_t)n);
+        ok = n == 0 || fread(buf.data(), 1, (size_t)n, f) == (size_t)n;
+    }
+    fclose(f);
+    return ok;
+}
+
+int slot_reserve(wd_ctx::IngestSlot *s, size_t need)
+{
+    if (!s->stream && hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking) != hipSuccess)
+        return WD_ERR_HIP;
+    if (need > s->cap) {
+        (void)hipHostFree(s->pinned);
+        s->pinned = nullptr;
+        s->cap = 0;
+        if (hipHostMalloc((void **)&s->pinned, need, hipHostMallocDefault) != hipSuccess)
+            return WD_ERR_NOMEM;
+        s->cap = need;
+    }
+    return WD_OK;
+}
+
+}  // namespace
+
+// These two may be called from several host threads at once on one context (each call leases
+// its own pinned buffer and copy stream); they do not touch the context's error string.
+int wd_load_bcl_gz(wd_ctx *ctx, const char *path, uint8_t *dst_dev, int64_t n_clusters)
+{
+    if (!ctx || !path || !dst_dev || n_clusters < 0)
+        return WD_ERR_ARG;
+    if (hipSetDevice(ctx->device) != hipSuccess)
+        return WD_ERR_HIP;
+    std::vector<uint8_t> raw;
+    if (!slurp(path, raw))
+        return WD_ERR_IO;                                  // FileNotFoundError in the reference
+    SlotLease lease(ctx);
+    const size_t want = (size_t)n_clusters + 4;
+    int rc = slot_reserve(lease.slot, want + 64);
+    if (rc)
+        return rc;
+    // gunzip (possibly several concatenated members) straight into the pinned buffer
+    z_stream zs;
+    memset(&zs, 0, sizeof(zs));
+    if (inflateInit2(&zs, 16 + MAX_WBITS) != Z_OK)
+        return WD_ERR_NOMEM;
+    zs.next_in = raw.data();
+    zs.avail_in = (uInt)std::min<size_t>(raw.size(), 0xFFFFFFFFu);
+    size_t produced = 0;
+    bool bad = raw.size() > 0xFFFFFFFFu;
+    while (!bad) {
+        zs.next_out = lease.slot->pinned + produced;
+        zs.avail_out = (uInt)std::min<size_t>(want + 64 - produced, 0x7FFFFFFFu);
+        const int zr = inflate(&zs, Z_NO_FLUSH);
+        produced = (size_t)(zs.next_out - lease.slot->pinned);
+        if (zr == Z_STREAM_END) {
+            if (zs.avail_in == 0)
+                break;
+            if (inflateReset(&zs) != Z_OK)
+                bad = true;
+            continue;
+        }
+        if (zr != Z_OK || zs.avail_out == 0) {
+            bad = zr != Z_OK;                              // avail_out == 0: more data than a plane
+            break;
+        }
+        if (zs.avail_in == 0)
+            break;                                         // truncated stream
+    }
+    inflateEnd(&zs);
+    if (bad)
+        return WD_ERR_IO;
+    if (produced < 4)
+        return WD_ERR_FORMAT;
+    uint32_t header;
+    memcpy(&header, lease.slot->pinned, 4);
+    if ((int64_t)header != n_clusters)                     // bcl_direct_reader.py:338
+        return WD_ERR_FORMAT;
+    if (produced < want)
+        return WD_ERR_INDEX;                               // the reference fails at slurped_file[idx]
+    if (n_clusters > 0) {
+        if (hipMemcpyAsync(dst_dev, lease.slot->pinned + 4, (size_t)n_clusters, hipMemcpyHostToDevice,
+                           lease.slot->stream) != hipSuccess ||
+            hipStreamSynchronize(lease.slot->stream) != hipSuccess)
+            return WD_ERR_HIP;
+    }
+    return WD_OK;
+}
+
+int wd_load_filter(wd_ctx *ctx, const char *path, uint8_t *dst_dev, int64_t n_clusters)
+{
+    if (!ctx || !path || !dst_dev || n_clusters < 0)
+        return WD_ERR_ARG;
+    if (hipSetDevice(ctx->device) != hipSuccess)
+        return WD_ERR_HIP;
+    std::vector<uint8_t> raw;
+    if (!slurp(path, raw))
+        return WD_ERR_IO;
+    if (raw.size() < 12)
+        return WD_ERR_FORMAT;
+    uint32_t head[3];
+    memcpy(head, raw.data(), 12);
+    if (head[0] != 0 || head[1] != 3 || (int64_t)head[2] != n_clusters)   // :148-152, :236
+        return WD_ERR_FORMAT;
+    if (raw.size() != 12 + (size_t)n_clusters)                            // :240
+        return WD_ERR_FORMAT;
+    SlotLease lease(ctx);
+    int rc = slot_reserve(lease.slot, (size_t)n_clusters + 64);
+    if (rc)
+        return rc;
+    if (n_clusters > 0) {
+        memcpy(lease.slot->pinned, raw.data() + 12, (size_t)n_clusters);
+        if (hipMemcpyAsync(dst_dev, lease.slot->pinned, (size_t)n_clusters, hipMemcpyHostToDevice,
+                           lease.slot->stream) != hipSuccess ||
+            hipStreamSynchronize(lease.slot->stream) != hipSuccess)
+            return WD_ERR_HIP;
+    }
+    return WD_OK;
+}
+
+int wd_gather_wells(wd_ctx *ctx, const uint8_t *const *planes, int L, const int32_t *idx, int64_t n,
+                    int64_t n_clusters, uint8_t *out_host)
+{
+    if (!ctx || L < 0 || n < 0 || (n > 0 && L > 0 && (!planes || !idx || !out_host)))
+        return fail(ctx, WD_ERR_ARG, "bad gather arguments");
+    for (int64_t i = 0; i < n; i++)
+        if (idx[i] < 0 || idx[i] >= n_clusters)
+            return fail(ctx, WD_ERR_INDEX, "well index outside the tile");
+    if (n == 0 || L == 0)
+        return WD_OK;
+    if (bind_device(ctx))
+        return WD_ERR_HIP;
+    const uint8_t **d_pl = nullptr;
+    int32_t *d_idx = nullptr;
+    uint8_t *d_out = nullptr;
+    int rc = WD_OK;
+    auto done = [&](int code, const char *msg) {
+        (void)hipFree(d_pl); (void)hipFree(d_idx); (void)hipFree(d_out);
+        return code == WD_OK ? WD_OK : fail(ctx, code, msg);
+    };
+    if (hipMalloc((void **)&d_pl, (size_t)L * sizeof(void *)) != hipSuccess ||
+        hipMalloc((void **)&d_idx, (size_t)n * 4) != hipSuccess ||
+        hipMalloc((void **)&d_out, (size_t)n * L) != hipSuccess)
+        return done(WD_ERR_NOMEM, "gather workspace");
+    if (hipMemcpyAsync(d_pl, planes, (size_t)L * sizeof(void *), hipMemcpyHostToDevice, ctx->stream) != hipSuccess ||
+        hipMemcpyAsync(d_idx, idx, (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream) != hipSuccess)
+        return done(WD_ERR_HIP, "gather upload");
+    const long long total = (long long)n * L;
+    hipLaunchKernelGGL(k_gather_wells, dim3((unsigned)((total + kBlock - 1) / kBlock)), dim3(kBlock), 0,
+                       ctx->stream, d_pl, L, d_idx, (long long)n, d_out);
+    if (hipGetLastError() != hipSuccess ||
+        hipMemcpyAsync(out_host, d_out, (size_t)total, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+        hipStreamSynchronize(ctx->stream) != hipSuccess)
+        return done(WD_ERR_HIP, "gather kernel");
+    (void)rc;
+    return done(WD_OK, "");
 }
 
 // ---- RCCL ----------------------------------------------------------------------------

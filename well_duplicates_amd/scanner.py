@@ -8,6 +8,7 @@ stride apart and every plane starts 256-byte aligned.
 from __future__ import annotations
 
 import ctypes
+import os
 from typing import Iterable, List, Optional, Sequence
 
 import numpy as np
@@ -37,6 +38,10 @@ def _raise(lib, ctx, rc: int):
         raise ValueError(msg)
     if rc == _lib.ERR_NOMEM:
         raise MemoryError(msg)
+    if rc == _lib.ERR_IO:
+        raise FileNotFoundError(msg)      # bcl_direct_reader.py:207-216
+    if rc == _lib.ERR_FORMAT:
+        raise AssertionError(msg)         # bcl_direct_reader.py:151, :236, :338
     raise RuntimeError(msg)
 
 
@@ -208,6 +213,29 @@ class Scanner:
 
     def scan_status(self):
         self._ck(self._lib.wd_scan_status(self._ctx))
+
+    # ------------------------------------------------------------------ ingest
+    def load_bcl_gz(self, path: str, dst: int, n_clusters: int):
+        """gunzip a .bcl.gz straight into device memory (thread-safe, releases the GIL)."""
+        rc = self._lib.wd_load_bcl_gz(self._ctx, os.fsencode(path), ctypes.c_void_p(dst), int(n_clusters))
+        if rc != _lib.OK:
+            _raise(self._lib, None, rc)
+
+    def load_filter(self, path: str, dst: int, n_clusters: int):
+        rc = self._lib.wd_load_filter(self._ctx, os.fsencode(path), ctypes.c_void_p(dst), int(n_clusters))
+        if rc != _lib.OK:
+            _raise(self._lib, None, rc)
+
+    def gather_wells(self, plane_ptrs: Sequence[int], idx, n_clusters: int) -> np.ndarray:
+        """uint8 [len(idx), L]: bytes of the given wells over the L planes."""
+        idx = np.ascontiguousarray(idx, dtype=np.int32)
+        L = len(plane_ptrs)
+        out = np.zeros((idx.shape[0], L), dtype=np.uint8)
+        tbl = (ctypes.c_void_p * max(1, L))(*[int(p) for p in plane_ptrs])
+        self._ck(self._lib.wd_gather_wells(self._ctx, tbl, L, idx.ctypes.data_as(ctypes.c_void_p),
+                                           idx.shape[0], int(n_clusters),
+                                           out.ctypes.data_as(ctypes.c_void_p)))
+        return out
 
     # ------------------------------------------------------------------ dup log / profile
     def hitlog_enable(self, capacity: int):
