@@ -172,6 +172,23 @@ struct ScanRare {
 using gbytes = const __attribute__((address_space(1))) uint8_t *;
 __device__ inline gbytes as_global(const uint8_t *p) { return (gbytes)p; }
 
+// Cache policy of the plane-byte loads.  On a pure one-byte-per-line gather non-temporal loads
+// (`global_load_ubyte ... nt`) reach 52.0 vs 47.1 G lines/s (tools/microbench_modes.hip; sc0 /
+// sc1 change nothing and no policy fetches less than the full 128-byte line) - but the scan
+// re-reads lines through L1/L2 (both slots of a pass, the centre's line, the drain rounds), and
+// with nt it ran 0.163 ms instead of 0.137 ms.  So: default policy; -DWD_NT_LOADS=1 to retry.
+#ifndef WD_NT_LOADS
+#define WD_NT_LOADS 0
+#endif
+__device__ inline uint32_t ldb(gbytes p, uint32_t i)
+{
+#if WD_NT_LOADS
+    return __builtin_nontemporal_load(p + i);
+#else
+    return p[i];
+#endif
+}
+
 // Symbol code of a BCL byte: 0 -> 4 ('N'), else byte & 3 (bcl_direct_reader.py:352-361).
 __device__ inline uint32_t code_of(uint32_t b)
 {
@@ -628,7 +645,7 @@ __device__ inline void q_drain(const QEnv &v, uint2 *q_a, uint2 *q_b, int &qn, i
                 for (int j0 = j; j0 < L && mm <= k; j0 += kWave) {
                     const int jj = j0 + lane;
                     gbytes p = q_plane<STRIDED>(v, min(jj, L - 1));
-                    const bool diff = code_of(p[idx]) != code_of(p[c]);
+                    const bool diff = code_of(ldb(p, idx)) != code_of(ldb(p, c));
                     mm += __popcll(__ballot(jj < L && diff));
                 }
                 if (mm <= k && lane == 0)
@@ -654,8 +671,8 @@ __device__ inline void q_drain(const QEnv &v, uint2 *q_a, uint2 *q_b, int &qn, i
                 for (int q = 0; q < MAXB; q++) {
                     if (q < nb) {
                         gbytes p = q_plane<STRIDED>(v, min(j + q, L - 1));
-                        w[q] = p[idx];
-                        cb[q] = p[c];
+                        w[q] = ldb(p, idx);
+                        cb[q] = ldb(p, c);
                     }
                 }
 #pragma unroll
@@ -832,8 +849,8 @@ __global__ __launch_bounds__(kBlock, 6) void k_scan_q(ScanArgs a)
             if (L > 0) {
 #pragma unroll
                 for (int q = 0; q < B1; q++) {
-                    w0_2[q] = pp[q][i0_2];
-                    w1_2[q] = pp[q][i1_2];
+                    w0_2[q] = ldb(pp[q], i0_2);
+                    w1_2[q] = ldb(pp[q], i1_2);
                 }
             }
             // stage A: neighbour indices of item s (clamped to the wave's last item)
