@@ -127,20 +127,35 @@ def main():
     tb.fill_synthetic(spec, lane_tile, list(range(L)))
     setup_s = time.time() - t0
 
-    # global counter block: every rank owns rows [rank*tiles, (rank+1)*tiles)
-    block = torch.zeros((world * args.tiles, ncnt), dtype=torch.int64, device="cuda")
-    my_rows = block[rank * args.tiles:(rank + 1) * args.tiles]
+    # global counter block: every rank owns rows [rank*tiles, (rank+1)*tiles).  Two of them:
+    # the all-reduce of step i (RCCL runs it on its own stream) overlaps the scan of step i+1,
+    # which writes the other block.
+    blocks = [torch.zeros((world * args.tiles, ncnt), dtype=torch.int64, device="cuda") for _ in range(2)]
+    pending = [None, None]
+    step_no = [0]
 
     def step():
+        b = step_no[0] & 1
+        step_no[0] += 1
+        block = blocks[b]
+        my_rows = block[rank * args.tiles:(rank + 1) * args.tiles]
         if use_dist:
+            if pending[b] is not None:
+                pending[b].wait()           # this block's previous all-reduce (two steps ago)
             block.zero_()
         sc.scan_async(tb.tables, args.tiles, L, n_clusters, mode, k, my_rows.data_ptr())
         if use_dist and not rehearsal:
-            dist.all_reduce(block)          # RCCL int64 sum over xGMI; rows are disjoint
+            # RCCL int64 sum over xGMI; the ranks' rows are disjoint
+            pending[b] = dist.all_reduce(block, async_op=True)
         elif use_dist:
             host = block.cpu()
             dist.all_reduce(host)
             block.copy_(host)
+
+    def finish_collectives():
+        for w in pending:
+            if w is not None:
+                w.wait()
 
     def fence():
         torch.cuda.synchronize()
@@ -150,16 +165,20 @@ def main():
 
     for _ in range(args.warmup):
         step()
+    finish_collectives()
     sc.scan_status()
     fence()
     t_start = time.perf_counter()
     for _ in range(args.steps):
         step()
+    finish_collectives()
     fence()
     elapsed = time.perf_counter() - t_start
     sc.scan_status()
     elapsed = wdist.max_over_ranks(elapsed, world, device="cpu" if rehearsal else "cuda")   # slowest rank
 
+    block = blocks[(step_no[0] - 1) & 1]                       # the last step's (merged) block
+    my_rows = block[rank * args.tiles:(rank + 1) * args.tiles]
     counts = block.cpu().numpy()
     compares_all = int(counts[:, 1:1 + levels].sum())          # sum of Wells over every rank
     mine = counts[rank * args.tiles:(rank + 1) * args.tiles]
