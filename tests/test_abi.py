@@ -63,7 +63,7 @@ def test_product_never_imports_oracle():
     root = os.path.dirname(_lib.HERE)
     for dirpath, _, files in os.walk(_lib.HERE):
         for f in files:
-            if f.endswith((".py", ".hip", ".h", ".cpp")):
+            if f.endswith((".py", ".hip", ".inc", ".h", ".cpp")):
                 src = open(os.path.join(dirpath, f)).read()
                 assert "import oracle" not in src and "from oracle" not in src, f
                 assert "libwelldup_oracle" not in src, f

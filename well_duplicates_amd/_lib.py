@@ -90,7 +90,9 @@ def build(force: bool = False, verbose: bool = False) -> str:
     """Compile csrc/welldup.hip for gfx950 into the package directory."""
     hdr = os.path.join(INCLUDE, "welldup.h")
     if not force and os.path.exists(LIB_PATH):
-        newest = max(os.path.getmtime(SRC), os.path.getmtime(hdr))
+        csrc = os.path.dirname(SRC)
+        newest = max([os.path.getmtime(hdr)] + [os.path.getmtime(os.path.join(csrc, f))
+                                                for f in os.listdir(csrc)])
         if os.path.getmtime(LIB_PATH) >= newest:
             return LIB_PATH
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
