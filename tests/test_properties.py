@@ -1,0 +1,72 @@
+"""Property tests (hypothesis) of the host logic: targets-file round trips and the tally
+reducer against the oracle's restatement of the reference's loops."""
+import io
+import os
+
+import numpy as np
+from hypothesis import given, settings, strategies as st
+
+from oracle import oracle
+from well_duplicates_amd import report
+from well_duplicates_amd.targets import load_targets
+
+ring = st.lists(st.integers(0, 5_000_000), min_size=2, max_size=12)     # a 1-element ring is ambiguous in the file format
+
+
+@st.composite
+def targets_files(draw):
+    levels = draw(st.integers(1, 6))
+    n = draw(st.integers(1, 12))
+    centres = draw(st.lists(st.integers(0, 5_000_000), min_size=n, max_size=n, unique=True))
+    return [[[c]] + [draw(ring) for _ in range(levels)] for c in centres]
+
+
+@settings(max_examples=60, deadline=None)
+@given(targets_files(), st.integers(0, 8), st.integers(0, 14))
+def test_targets_file_roundtrip(tmp_path_factory, recs, cut_levels, limit):
+    path = os.path.join(str(tmp_path_factory.mktemp("t")), "x.list")
+    with open(path, "w") as fh:
+        for rec in recs:
+            for line in rec:
+                fh.write(",".join(map(str, line)) + "\n")
+    have = len(recs[0])
+    keep = None if cut_levels == 0 else min(cut_levels, have)
+    t = load_targets(path, levels=keep, limit=limit or None)
+    want = oracle.py_load_targets(path, levels=keep, limit=limit or None)
+    assert [x.coords for x in t] == want
+    n = len(recs) if not limit else min(limit, len(recs))
+    assert len(t) == n
+    lv = (keep or have) - 1
+    centre, lvl_off, nbr = t.to_csr(lv)
+    for i, rec in enumerate(recs[:n]):
+        assert centre[i] == rec[0][0]
+        for l in range(1, lv + 1):
+            assert nbr[lvl_off[i, l - 1]:lvl_off[i, l]].tolist() == rec[l]
+    assert set(t.get_all_indices()) == {w for rec in recs[:n] for line in rec[:lv + 1] for w in line}
+
+
+stats = st.lists(st.lists(st.tuples(st.integers(0, 4).map(lambda v: v if v < 3 else 0), st.integers(1, 40)),
+                          min_size=4, max_size=4), min_size=0, max_size=15)
+
+
+@settings(max_examples=80, deadline=None)
+@given(st.dictionaries(st.sampled_from(["1101", "1102", "1203", "2228", "2101"]), stats, min_size=1, max_size=4),
+       st.booleans(), st.integers(0, 4))
+def test_report_equals_reference_restatement(lane_dupl, verbose, levels):
+    """Same text (or the same ZeroDivisionError) as the restated output_writer."""
+    try:
+        want = oracle.py_output_writer("3", 7, lane_dupl, levels=levels, verbose=verbose)
+    except ZeroDivisionError:
+        want = None
+    buf = io.StringIO()
+    try:
+        report.output_writer("3", 7, lane_dupl, levels=levels, verbose=verbose, out=buf, strict=True)
+        got = buf.getvalue()
+    except ZeroDivisionError:
+        got = None
+    assert got == want
+    # the graceful (non-strict) printer never raises and agrees whenever the reference survives
+    buf2 = io.StringIO()
+    report.output_writer("3", 7, lane_dupl, levels=levels, verbose=verbose, out=buf2)
+    if want is not None:
+        assert buf2.getvalue() == want
