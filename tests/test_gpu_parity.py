@@ -391,6 +391,68 @@ def test_dense_all_centres_small(sc):
     tb.free()
 
 
+def test_less_travelled_paths(sc):
+    """Pointer-table plane layout x {dense kernel, generic Levenshtein}, their hit logs, empty
+    rings under the dense kernel, and scans without the per-target output."""
+    rng = np.random.default_rng(77)
+    spec = synth.SynthSpec(seed=41, n_clusters=8009, row=97, plant_per_64k=25000, plant_far=True,
+                           nocall_per_64k=2500)
+    T, levels, L = 400, 3, 30
+    centre, lvl_off, nbr = _random_case(rng, spec.n_clusters, T, levels, ring=12)
+    sc.set_targets(centre, lvl_off, nbr)
+    tb = TileBatch(sc, 2, L, spec.n_clusters)
+    tiles = [(1, 1101), (1, 1102)]
+    tb.fill_synthetic(spec, tiles, list(range(L)))
+    n = spec.n_clusters
+    slab = sc.malloc(2 * L * (n + 7) + 64)
+    ptrs = [[slab + 3 + (i * L + c) * (n + 7) for c in range(L)] for i in range(2)]
+    for i in range(2):
+        for c in range(L):
+            sc.h2d(ptrs[i][c], tb.download_plane(i, c))
+    host = [compact_tile(spec, lane, tile, list(range(L)), centre, nbr) for lane, tile in tiles]
+    try:
+        for mode, k, dense in ((0, 0, 1), (1, 1, 1), (2, 20, -1), (2, 25, -1)):
+            sc.set_option("dense_kernel", dense)
+            sc.hitlog_enable(200000)
+            bl, pt = sc.count_tiles(ptrs, tb.filter_ptrs(), n, mode, k, per_target=True)
+            hits, total = sc.hitlog_fetch(200000)
+            sc.hitlog_enable(0)
+            bl2, none = sc.count_tiles(ptrs, tb.filter_ptrs(), n, mode, k)     # no per-target output
+            assert none is None and (bl2 == bl).all()
+            bl3, pt3 = tb.count(mode, k, per_target=True)                       # strided layout
+            assert (bl3 == bl).all() and (pt3 == pt).all()
+            want_hits = []
+            for i in range(2):
+                planes, filt, c2, n2, _ = host[i]
+                valid, dups, lens, dist = oracle.count_tile(planes, filt, c2, lvl_off, n2, mode, k,
+                                                            want_dist=True)
+                got = pt[i].astype(np.int64)
+                got[got == INVALID_TARGET] = -1
+                assert (got == np.where(valid[:, None] == 1, dups, -1)).all(), (mode, k, dense)
+                assert (blocks_to_reference(bl[i], levels) == oracle.tally_tile(valid, dups, lens)).all()
+                kk = 0 if mode == 0 else k
+                for t in range(T):
+                    if valid[t]:
+                        for p in range(lvl_off[t, 0], lvl_off[t, levels]):
+                            if dist[p] <= kk:
+                                want_hits.append((i, t, p, int(dist[p])))
+            assert total == len(want_hits)
+            assert sorted((int(h["tile"]), int(h["target"]), int(h["slot"]), int(h["dist"])) for h in hits) \
+                == sorted(want_hits)
+        # an empty ring under a valid centre, dense kernel: AssertionError as the reference
+        filt = synth.filter_bytes(spec, 1, 1101)
+        good = int(np.flatnonzero(filt & 1)[0])
+        sc.set_targets(np.array([good, good + 1], np.int32), np.array([[0, 1, 1], [1, 2, 3]], np.int32),
+                       np.array([3, 4, 5], np.int32))
+        sc.set_option("dense_kernel", 1)
+        with pytest.raises(AssertionError):
+            tb.count(0, 0)
+    finally:
+        sc.set_option("dense_kernel", -1)
+        sc.free(slab)
+        tb.free()
+
+
 def test_fresh_context_requires_targets():
     s = Scanner(0)
     with pytest.raises(RuntimeError):
