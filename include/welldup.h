@@ -230,6 +230,7 @@ typedef struct wd_synth_spec {
     uint32_t filter_noise;
     uint32_t tile_dead;
     uint32_t plant_far;
+    uint32_t qual_levels;     /* distinct quality values (0 = 39) */
 } wd_synth_spec;
 int wd_synth_plane(wd_ctx *ctx, uint8_t *dst_dev, const wd_synth_spec *spec, int lane, int tile,
                    int cycle);

@@ -44,6 +44,7 @@ def test_synth_device_matches_numpy(sc):
                              nocall_per_64k=1500, filter_noise=True), 2, 1203),
             (synth.SynthSpec(seed=1, n_clusters=70001, row=1571), 1, 1101),
             (synth.SynthSpec(seed=8, n_clusters=50021, row=173, plant_per_64k=20000, plant_far=True), 4, 2101),
+            (synth.SynthSpec(seed=9, n_clusters=30011, row=173, qual_levels=7), 2, 1105),
             (synth.SynthSpec(seed=5, n_clusters=4096, row=64, dead_tiles=(2205,)), 8, 2205)):
         cycles = [0, 1, 2, 50, 126, 127, 128, 149]
         tb = TileBatch(sc, 1, len(cycles), spec.n_clusters)

@@ -22,17 +22,19 @@ def main():
     ap.add_argument("--dir", default="/tmp/wd_e2e")
     ap.add_argument("--threads", type=int, default=16)
     ap.add_argument("--extra", default="")
+    ap.add_argument("--qual-levels", type=int, default=7, help="binned qualities -> compressible planes")
+    ap.add_argument("--gzip-level", type=int, default=6)
     a = ap.parse_args()
     rows, cols = workload.HISEQ4000_ROWS, workload.HISEQ4000_COLS
-    spec = synth.SynthSpec(seed=2, n_clusters=rows * cols, row=cols)
+    spec = synth.SynthSpec(seed=2, n_clusters=rows * cols, row=cols, qual_levels=a.qual_levels)
     tiles = workload.tiles_for_stype("hiseq_x")[:a.tiles]
-    marker = os.path.join(a.dir, "done_%d_%d" % (a.tiles, a.cycles))
+    marker = os.path.join(a.dir, "done_%d_%d_%d_%d" % (a.tiles, a.cycles, a.qual_levels, a.gzip_level))
     tfile = os.path.join(a.dir, "targets.list")
     if not os.path.exists(marker):
         t0 = time.time()
         os.makedirs(a.dir, exist_ok=True)
         x, y = synth.honeycomb_pixels(rows, cols)
-        synth.write_run_dir(spec, a.dir, [1], tiles, list(range(a.cycles)))
+        synth.write_run_dir(spec, a.dir, [1], tiles, list(range(a.cycles)), compresslevel=a.gzip_level)
         centres = cluster_indexes.sample_centres(rows * cols, 2500, 13)
         with open(tfile, "w") as fh:
             cluster_indexes.write_targets(cluster_indexes.generate(x, y, centres, 5), fh)

@@ -35,7 +35,8 @@ class SynthSpecC(ctypes.Structure):
     _fields_ = [("seed", ctypes.c_uint64), ("n_clusters", ctypes.c_int64), ("row", ctypes.c_int64),
                 ("nocall_per_64k", ctypes.c_uint32), ("pass_per_64k", ctypes.c_uint32),
                 ("plant_per_64k", ctypes.c_uint32), ("filter_noise", ctypes.c_uint32),
-                ("tile_dead", ctypes.c_uint32), ("plant_far", ctypes.c_uint32)]
+                ("tile_dead", ctypes.c_uint32), ("plant_far", ctypes.c_uint32),
+                ("qual_levels", ctypes.c_uint32)]
 
 
 _vp = ctypes.c_void_p

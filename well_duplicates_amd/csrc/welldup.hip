@@ -1368,6 +1368,7 @@ int wd_synth_plane(wd_ctx *ctx, uint8_t *dst_dev, const wd_synth_spec *spec, int
     a.nocall = spec->nocall_per_64k;
     a.plant = spec->plant_per_64k;
     a.far = spec->plant_far;
+    a.qlev = spec->qual_levels ? spec->qual_levels : 39u;
     a.cycle = cycle;
     if (a.n == 0)
         return WD_OK;

@@ -282,7 +282,7 @@ class Scanner:
         return _lib.SynthSpecC(spec.seed, spec.n_clusters, spec.row, spec.nocall_per_64k,
                                spec.pass_per_64k, spec.plant_per_64k, int(spec.filter_noise),
                                int(int(tile) in tuple(int(t) for t in spec.dead_tiles)),
-                               int(spec.plant_far))
+                               int(spec.plant_far), int(spec.qual_levels))
 
     def synth_plane(self, dst: int, spec, lane: int, tile: int, cycle: int):
         s = self._spec_c(spec, tile)

@@ -78,6 +78,8 @@ class SynthSpec:
     filter_noise: bool = False         # set filter bit 1 at random (tests `flag & 1`)
     dead_tiles: tuple = ()             # tile numbers whose every cluster fails the filter
     plant_far: bool = False            # copies from up to 5 rows / 3 wells away (outer levels)
+    qual_levels: int = 39              # distinct quality values; 7-8 mimics binned qualities
+                                       # (and makes the planes compress ~2x, like real .bcl.gz)
 
     def tile_key(self, lane: int, tile: int, salt: int) -> int:
         return mix64_int(self.seed * K_SEED + lane * K_LANE + tile * K_TILE + salt)
@@ -93,7 +95,7 @@ def _raw_bytes(spec: SynthSpec, plane_key: int, clusters: np.ndarray) -> np.ndar
         h = mix64(np.uint64(plane_key) + clusters.astype(np.uint64) * np.uint64(K_CLUSTER))
     nocall = (h & np.uint64(0xFFFF)) < np.uint64(spec.nocall_per_64k)
     base = (h >> np.uint64(16)) & np.uint64(3)
-    qual = np.uint64(2) + ((h >> np.uint64(18)) & np.uint64(0xFFFF)) % np.uint64(39)
+    qual = np.uint64(2) + ((h >> np.uint64(18)) & np.uint64(0xFFFF)) % np.uint64(spec.qual_levels)
     b = ((qual << np.uint64(2)) | base).astype(np.uint8)
     b[nocall] = 0
     return b
