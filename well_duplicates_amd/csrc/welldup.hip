@@ -232,7 +232,10 @@ void drain_events(wd_ctx *ctx)
 // is instantiated for a few shapes so they can be tuned; the banded edit-distance family
 // needs ~2x the cycles before a random neighbour dies, so it uses one deeper shape.
 constexpr int kHamShapes[][2] = {{2, 4}, {3, 4}, {4, 4}, {4, 8}, {8, 8}};
-constexpr int kLevB1 = 8, kLevB2 = 8;
+// first-round depth per band half-width H: where ~2-4 % of random neighbours are still alive
+// under LevState::alive's lag-free criterion (k = 2H or 2H+1)
+constexpr int lev_first(int H) { return H == 1 ? 7 : H == 2 ? 10 : H == 3 ? 13 : H == 4 ? 16 : H <= 6 ? 20 : 24; }
+constexpr int kLevB2 = 8;
 
 template <bool STRIDED>
 void launch_ham(wd_ctx *ctx, const ScanArgs &a, dim3 grid)
@@ -256,10 +259,10 @@ template <int H>
 void launch_lev(wd_ctx *ctx, const ScanArgs &a, dim3 grid, bool strided)
 {
     if (strided)
-        hipLaunchKernelGGL((k_scan<LevState<H>, true, kLevB1, kLevB2>), grid, dim3(kBlock), 0,
+        hipLaunchKernelGGL((k_scan<LevState<H>, true, lev_first(H), kLevB2>), grid, dim3(kBlock), 0,
                            ctx->stream, a);
     else
-        hipLaunchKernelGGL((k_scan<LevState<H>, false, kLevB1, kLevB2>), grid, dim3(kBlock), 0,
+        hipLaunchKernelGGL((k_scan<LevState<H>, false, lev_first(H), kLevB2>), grid, dim3(kBlock), 0,
                            ctx->stream, a);
 }
 
