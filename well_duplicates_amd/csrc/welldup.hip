@@ -34,6 +34,7 @@
 
 #include <algorithm>
 #include <mutex>
+#include <type_traits>
 #include <string>
 #include <vector>
 
@@ -324,6 +325,13 @@ int ensure_dense_tables(wd_ctx *ctx)
     WD_HIP(ctx, hipGetLastError());
     WD_HIP(ctx, hipStreamSynchronize(ctx->stream));       // h_gbase may be reused by the caller
     return WD_OK;
+}
+
+template <bool STRIDED, int H>
+void launch_queue_lev(wd_ctx *ctx, const ScanArgs &a, dim3 grid)
+{
+    const size_t lds = (size_t)scan_q_lds_dwords(a.levels, a.tpb, 4) * sizeof(uint32_t);
+    hipLaunchKernelGGL((k_scan_q<STRIDED, lev_first(H), H>), grid, dim3(kBlock), lds, ctx->stream, a);
 }
 
 bool valid_batches(int b1, int b2)
@@ -796,6 +804,14 @@ int wd_scan_async(wd_ctx *ctx, int n_tiles, int L, int mode, int k, const uint8_
             launch_ham<true>(ctx, a, grid);
         else
             launch_ham<false>(ctx, a, grid);
+    } else if (lev && !lev_generic && kk / 2 <= 3 && ctx->queue_kernel && ctx->early_exit &&
+               ctx->k_max <= (int64_t)kMaxPasses * kPass) {
+        // Levenshtein <= k, k = 2..7 (the reference's default is 2): queue kernel, DP state in
+        // the queue entries
+        const int h = kk / 2;
+        if (h <= 1) { if (strided) launch_queue_lev<true, 1>(ctx, a, grid); else launch_queue_lev<false, 1>(ctx, a, grid); }
+        else if (h == 2) { if (strided) launch_queue_lev<true, 2>(ctx, a, grid); else launch_queue_lev<false, 2>(ctx, a, grid); }
+        else { if (strided) launch_queue_lev<true, 3>(ctx, a, grid); else launch_queue_lev<false, 3>(ctx, a, grid); }
     } else if (lev_generic) {
         const int h = kk / 2;
         const size_t lds = lev_generic_lds_bytes(L, h);
