@@ -235,7 +235,10 @@ void drain_events(wd_ctx *ctx)
 constexpr int kHamShapes[][2] = {{2, 4}, {3, 4}, {4, 4}, {4, 8}, {8, 8}};
 // first-round depth per band half-width H: where ~2-4 % of random neighbours are still alive
 // under LevState::alive's lag-free criterion (k = 2H or 2H+1)
-constexpr int lev_first(int H) { return H == 1 ? 7 : H == 2 ? 10 : H == 3 ? 13 : H == 4 ? 16 : H <= 6 ? 20 : 24; }
+#ifndef WD_LEV_FIRST_H1
+#define WD_LEV_FIRST_H1 7
+#endif
+constexpr int lev_first(int H) { return H == 1 ? WD_LEV_FIRST_H1 : H == 2 ? 10 : H == 3 ? 13 : H == 4 ? 16 : H <= 6 ? 20 : 24; }
 constexpr int kLevB2 = 8;
 
 template <bool STRIDED>
