@@ -278,7 +278,7 @@ int launch_queue(wd_ctx *ctx, const ScanArgs &a, dim3 grid)
     // sum_{i<=k} C(r,i) 0.75^i 0.25^(r-i); the first round should leave a few percent alive.
     int first = ctx->queue_first;
     if (first == 0)
-        first = a.k <= 0 ? 2 : (a.k <= 2 ? 4 : (a.k == 3 ? 6 : 8));   // measured on MI355X
+        first = a.k <= 0 ? 2 : (a.k == 1 ? 4 : (a.k <= 3 ? 6 : 8));   // measured on MI355X
     switch (first) {
     case 1: hipLaunchKernelGGL((k_scan_q<STRIDED, 1>), grid, dim3(kBlock), lds, ctx->stream, a); break;
     case 2: hipLaunchKernelGGL((k_scan_q<STRIDED, 2>), grid, dim3(kBlock), lds, ctx->stream, a); break;
