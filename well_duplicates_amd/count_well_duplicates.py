@@ -20,7 +20,7 @@ Differences from the reference, all deliberate:
     ZeroDivisionError (F5); --strict restores the exception;
   * `-t` with a pattern that matches nothing raises the AssertionError the reference
     intends (its own message formatting raises NameError first);
-  * extra flags: --device, --tile-batch, --threads, --strict.
+  * extra flags: --device, --dist-backend, --tile-batch, --threads, --strict, -o/--output.
 """
 from __future__ import annotations
 
@@ -90,6 +90,8 @@ def parse_args(argv=None):
                    help="tiles kept resident in HBM and scanned per launch")
     p.add_argument("--threads", type=int, default=min(16, os.cpu_count() or 1),
                    help="reader threads (gunzip)")
+    p.add_argument("-o", "--output", default=None,
+                   help="write the report to this file instead of stdout")
     p.add_argument("--strict", action="store_true",
                    help="reproduce the reference's ZeroDivisionError on a lane without duplicates")
     return p.parse_args(argv)
@@ -204,6 +206,7 @@ def main(argv=None):
         else:
             tdist.init_process_group("gloo")
     levels = args.level
+    out_fh = open(args.output, "w") if (args.output and rank == 0) else None
     try:
         with Scanner(device) as sc:
             sc.set_targets(*csr)
@@ -230,8 +233,10 @@ def main(argv=None):
                         for line in logs.get(t, ()):
                             log(line)
                     report.write_report(lane, len(targets), counts, verbose=not args.summary_only,
-                                        strict=args.strict)
+                                        strict=args.strict, out=out_fh)
     finally:
+        if out_fh:
+            out_fh.close()
         if world > 1:
             import torch.distributed as tdist
             tdist.destroy_process_group()
