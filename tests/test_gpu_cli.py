@@ -81,8 +81,12 @@ def test_cli_two_ranks_one_gpu(tmp_path_factory, tmp_path):
     report_file = str(tmp_path / "report.txt")
     argv += run["flags"] + ["--device", "0", "--dist-backend", "gloo", "-o", report_file]
     repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
     res = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
-                          "--master-addr", "127.0.0.1", "--master-port", "29541",
+                          "--master-addr", "127.0.0.1", "--master-port", str(port),
                           "-m", "well_duplicates_amd.count_well_duplicates"] + argv,
                          cwd=repo, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
     assert res.returncode == 0, res.stderr.decode()[-2000:]
