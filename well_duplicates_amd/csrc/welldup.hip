@@ -334,7 +334,11 @@ template <bool STRIDED, int H>
 void launch_queue_lev(wd_ctx *ctx, const ScanArgs &a, dim3 grid)
 {
     const size_t lds = (size_t)scan_q_lds_dwords(a.levels, a.tpb, 4) * sizeof(uint32_t);
-    hipLaunchKernelGGL((k_scan_q<STRIDED, lev_first(H), H>), grid, dim3(kBlock), lds, ctx->stream, a);
+    // an odd threshold (k = 2H + 1) keeps random neighbours alive about one cycle longer
+    if (a.k & 1)
+        hipLaunchKernelGGL((k_scan_q<STRIDED, lev_first(H) + 1, H>), grid, dim3(kBlock), lds, ctx->stream, a);
+    else
+        hipLaunchKernelGGL((k_scan_q<STRIDED, lev_first(H), H>), grid, dim3(kBlock), lds, ctx->stream, a);
 }
 
 bool valid_batches(int b1, int b2)
