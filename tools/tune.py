@@ -30,10 +30,15 @@ def main():
     ap.add_argument("--rounds", type=int, default=5)
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--variants", default="tpb=8,b1=4,b2=8")
+    ap.add_argument("--sort-nbr", action="store_true",
+                    help="experiment: sort every target's neighbour list by well index (tallies become meaningless)")
     args = ap.parse_args()
     rows, cols = workload.HISEQ4000_ROWS, workload.HISEQ4000_COLS
     n = rows * cols
     centre, lvl_off, nbr = workload.honeycomb_targets(rows, cols, args.targets, args.levels, 13)
+    if args.sort_nbr:
+        for t in range(centre.shape[0]):
+            nbr[lvl_off[t, 0]:lvl_off[t, -1]] = np.sort(nbr[lvl_off[t, 0]:lvl_off[t, -1]])
     spec = synth.SynthSpec(seed=2, n_clusters=n, row=cols)
     tiles = [int(t) for t in workload.tiles_for_stype("hiseq_x")][:args.tiles]
     sc = Scanner(0)

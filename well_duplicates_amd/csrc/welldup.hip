@@ -979,10 +979,10 @@ int wd_targets_from_coords(wd_ctx *ctx, const int32_t *x, const int32_t *y, int6
         return WD_ERR_HIP;
     WD_HIP(ctx, hipStreamSynchronize(ctx->stream));
     const int T = (int)n_centres;
-    int32_t *d_x = nullptr, *d_y = nullptr, *d_c = nullptr, *d_counts = nullptr;
+    int32_t *d_x = nullptr, *d_y = nullptr, *d_counts = nullptr;
     int32_t *d_off = nullptr, *d_nbr = nullptr, *d_centre = nullptr;
     auto cleanup = [&]() {
-        (void)hipFree(d_x); (void)hipFree(d_y); (void)hipFree(d_c); (void)hipFree(d_counts);
+        (void)hipFree(d_x); (void)hipFree(d_y); (void)hipFree(d_counts);
     };
     auto bail = [&](int code, const std::string &msg) {
         cleanup();
@@ -1003,7 +1003,6 @@ int wd_targets_from_coords(wd_ctx *ctx, const int32_t *x, const int32_t *y, int6
     WD_GEN_HIP(hipMalloc((void **)&d_centre, std::max<size_t>(1, T) * 4));
     if (centres) {
         WD_GEN_HIP(hipMemcpy(d_centre, centres, (size_t)T * 4, hipMemcpyHostToDevice));
-        d_c = nullptr;
     } else {
         std::vector<int32_t> iota((size_t)T);
         for (int i = 0; i < T; i++)
