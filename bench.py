@@ -41,7 +41,10 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--tiles", type=int, default=96, help="tiles per rank (one lane)")
+    ap.add_argument("--tiles", type=int, default=None,
+                    help="tiles per rank (one lane); default: all tiles of --stype (96 / 112)")
+    ap.add_argument("--stype", default="hiseq_x", choices=["hiseq_x", "hiseq_4000"],
+                    help="lane layout: hiseq_x = 96 tiles (BASELINE configs[1]), hiseq_4000 = 112 (configs[2])")
     ap.add_argument("--targets", type=int, default=2500)
     ap.add_argument("--levels", type=int, default=5)
     ap.add_argument("--bases", type=int, default=50)
@@ -104,10 +107,13 @@ def main():
     centre, lvl_off, nbr = workload.honeycomb_targets(rows, cols, T, levels, seed=13)
     spec = synth.SynthSpec(seed=2, n_clusters=n_clusters, row=cols)
     lane = rank + 1
-    tile_ids = [int(t) for t in workload.tiles_for_stype(workload.HISEQ_X)]
-    tile_ids = (tile_ids * ((args.tiles + len(tile_ids) - 1) // len(tile_ids)))[:args.tiles]
-    # repeated ids (only if --tiles > 96) get distinct lanes so no two tiles share data
-    lane_tile = [(lane + 8 * (i // 96), t) for i, t in enumerate(tile_ids)]
+    tile_ids = [int(t) for t in workload.tiles_for_stype(args.stype)]
+    if args.tiles is None:
+        args.tiles = len(tile_ids)
+    per_lane = len(tile_ids)
+    tile_ids = (tile_ids * ((args.tiles + per_lane - 1) // per_lane))[:args.tiles]
+    # repeated ids (only if --tiles exceeds a lane) get distinct lanes so no two tiles share data
+    lane_tile = [(lane + 8 * (i // per_lane), t) for i, t in enumerate(tile_ids)]
 
     # One explicit stream for everything in a step (scan kernels, torch ops, the collective's
     # stream dependencies).  The scanner must NOT be left on its own stream here: torch's
