@@ -184,6 +184,14 @@ int wd_scan_status(wd_ctx *ctx);
  */
 int wd_load_bcl_gz(wd_ctx *ctx, const char *path, uint8_t *dst_dev, int64_t n_clusters);
 int wd_load_filter(wd_ctx *ctx, const char *path, uint8_t *dst_dev, int64_t n_clusters);
+/* NovaSeq: one tile's block of a `L00<lane>_<surface>.cbcl` file -> an n_clusters-byte plane on
+ * the device, replacing _get_seqs_from_cbcl (bcl_direct_reader.py:255-325): header and tile
+ * table checks (:263-295, WD_ERR_FORMAT), gunzip of the tile's block (:300-301), nibble
+ * expansion on the GPU (:316-321) including the excluded-wells indirection through the tile's
+ * filter (:303-314; filter_dev must already hold the tile's filter bytes).  Thread-safe like
+ * wd_load_bcl_gz. */
+int wd_load_cbcl_tile(wd_ctx *ctx, const char *path, int tile_number, const uint8_t *filter_dev,
+                      int64_t n_clusters, uint8_t *dst_dev);
 int wd_gather_wells(wd_ctx *ctx, const uint8_t *const *planes, int L, const int32_t *idx, int64_t n,
                     int64_t n_clusters, uint8_t *out_host);
 

@@ -88,3 +88,42 @@ def test_errors_and_odd_files(sc, run_dir, tmp_path):
     with pytest.raises(AssertionError):                          # :151
         sc.load_filter(str(f), dst, 5)
     sc.free(dst)
+
+
+@pytest.mark.parametrize("excluded", [False, True])
+def test_cbcl_native_equals_host_reader(sc, tmp_path, excluded):
+    """wd_load_cbcl_tile (gunzip on the host, nibble expansion + excluded-wells ranks on the GPU)
+    gives the same base codes and no-calls as the host reader of bcl_direct_reader.py:255-325."""
+    from well_duplicates_amd import bcl
+    n = 70001                                               # odd; 69 chunks of 1024 wells
+    spec = synth.SynthSpec(seed=12, n_clusters=n, row=211, nocall_per_64k=5000, pass_per_64k=40000)
+    tiles = ["1101", "1150", "2103"]
+    cycles = list(range(3))
+    synth.write_run_dir_cbcl(spec, str(tmp_path), [2], tiles, cycles, excluded=excluded)
+    rd = bcl.BCLReader(str(tmp_path))
+    tb = TileBatch(sc, len(tiles), len(cycles), n)
+    handles = [rd.get_tile(2, t) for t in tiles]
+    for i, h in enumerate(handles):
+        sc.load_filter(h.filter_file, tb.filter_ptr(i), n)
+    jobs = [(i, c) for i in range(len(tiles)) for c in cycles]
+    with ThreadPoolExecutor(max_workers=6) as pool:
+        list(pool.map(lambda j: sc.load_cbcl_tile(handles[j[0]].cbcl_path(j[1]), int(tiles[j[0]]),
+                                                  tb.filter_ptr(j[0]), n, tb.plane_ptr(j[0], j[1])), jobs))
+    for i, h in enumerate(handles):
+        for c in cycles:
+            got = tb.download_plane(i, c)
+            want = h.read_plane(c)
+            assert (np.where(got == 0, 4, got & 3) == np.where(want == 0, 4, want & 3)).all()
+            if excluded:
+                assert (got[(synth.filter_bytes(spec, 2, int(tiles[i])) & 1) == 0] == 0).all()
+    with pytest.raises(AssertionError):                     # tile not in the table (:295)
+        sc.load_cbcl_tile(handles[0].cbcl_path(0), 1199, tb.filter_ptr(0), n, tb.plane_ptr(0, 0))
+    with pytest.raises(FileNotFoundError):
+        sc.load_cbcl_tile(str(tmp_path / "nope.cbcl"), 1101, tb.filter_ptr(0), n, tb.plane_ptr(0, 0))
+    bad = tmp_path / "bad.cbcl"
+    raw = bytearray(open(handles[0].cbcl_path(0), "rb").read())
+    raw[0] = 2                                              # version != 1 (:266)
+    bad.write_bytes(bytes(raw))
+    with pytest.raises(AssertionError):
+        sc.load_cbcl_tile(str(bad), 1101, tb.filter_ptr(0), n, tb.plane_ptr(0, 0))
+    tb.free()

@@ -106,6 +106,10 @@ class Tile:
         """Path of the .bcl.gz of 0-based `cycle` (it may not exist: NovaSeq runs have .cbcl)."""
         return os.path.join(self.data_dir, "C%i.1" % (cycle + 1), self.bcl_filename)
 
+    def cbcl_path(self, cycle: int) -> str:
+        """Path of the lane/surface .cbcl of 0-based `cycle` (NovaSeq layout, :137)."""
+        return os.path.join(self.data_dir, "C%i.1" % (cycle + 1), self.cbcl_filename)
+
     def read_plane(self, cycle: int) -> np.ndarray:
         """N base-call bytes of 0-based `cycle` (directory C<cycle+1>.1, :201)."""
         cycle_dir = os.path.join(self.data_dir, "C%i.1" % (cycle + 1))

@@ -128,20 +128,21 @@ def scan_lane(sc: Scanner, reader, lane, tiles, cycle_list, mode, k, csr, wells,
             # ingest: every (tile, cycle) file is gunzipped into pinned memory and copied to
             # the GPU by libwelldup (wd_load_bcl_gz; the ctypes call releases the GIL, so the
             # pool's threads overlap gunzip, PCIe and each other).  Runs without .bcl.gz files
-            # (NovaSeq .cbcl) fall back to the Python reader + a plain upload.
+            # are NovaSeq runs: the tile's block of the lane/surface .cbcl is gunzipped on the
+            # host and expanded on the GPU (wd_load_cbcl_tile), which needs the filter first.
+            for i, h in enumerate(handles):
+                sc.load_filter(h.filter_file, tb.filter_ptr(i), n_clusters)
+
             def load(job):
                 i, c = job
                 try:
                     sc.load_bcl_gz(handles[i].plane_path(cycle_list[c]), tb.plane_ptr(i, c), n_clusters)
-                    return None
                 except FileNotFoundError:
-                    return handles[i].read_plane(cycle_list[c])
+                    sc.load_cbcl_tile(handles[i].cbcl_path(cycle_list[c]), int(handles[i].tile),
+                                      tb.filter_ptr(i), n_clusters, tb.plane_ptr(i, c))
             jobs = [(i, c) for i in range(len(handles)) for c in range(len(cycle_list))]
-            for (i, c), plane in zip(jobs, pool.map(load, jobs)):
-                if plane is not None:
-                    sc.h2d(tb.plane_ptr(i, c), plane)
+            list(pool.map(load, jobs))
             for i, h in enumerate(handles):
-                sc.load_filter(h.filter_file, tb.filter_ptr(i), n_clusters)
                 if want_log and wells.size:
                     # only the bytes of wells some target touches come back, for the stderr log
                     seq_bytes[i] = sc.gather_wells([tb.plane_ptr(i, c) for c in range(len(cycle_list))],

@@ -226,6 +226,13 @@ class Scanner:
         if rc != _lib.OK:
             _raise(self._lib, None, rc)
 
+    def load_cbcl_tile(self, path: str, tile: int, filter_dev: int, n_clusters: int, dst: int):
+        """One tile's block of a NovaSeq .cbcl file -> byte plane on the device (thread-safe)."""
+        rc = self._lib.wd_load_cbcl_tile(self._ctx, os.fsencode(path), int(tile),
+                                         ctypes.c_void_p(filter_dev), int(n_clusters), ctypes.c_void_p(dst))
+        if rc != _lib.OK:
+            _raise(self._lib, None, rc)
+
     def gather_wells(self, plane_ptrs: Sequence[int], idx, n_clusters: int) -> np.ndarray:
         """uint8 [len(idx), L]: bytes of the given wells over the L planes."""
         idx = np.ascontiguousarray(idx, dtype=np.int32)
