@@ -8,8 +8,10 @@ and filters generated on the device from the counter-based spec (well_duplicates
 0.5 % no-calls, 70 % filter pass, 2 % planted near-duplicates).  Rank r scans lane r+1.
 
 A "step" is one pass of the scan path over the rank's 96 resident tiles (all kernels of
-wd_scan_async) plus, for N > 1, the one int64 all-reduce of the [lanes*tiles, 1+5*levels]
-counter block.  Inputs are resident in HBM before the timed region.  One unit of work is one
+wd_scan_async) into that step's rows of the job's counter block.  For N > 1 the ranks' rows are
+merged inside the timed region by one int64 all-reduce of the [steps, lanes*tiles, 1+5*levels]
+block per job (ONE collective per job, as in the CLI; `--merge-every 1` merges
+after every step instead).  Inputs are resident in HBM before the timed region.  One unit of work is one
 performed compare = one unit of the reference report's `Wells` column
 (count_well_duplicates.py:93), read back from the device's own counters.
 
@@ -56,6 +58,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-steps", type=int, default=20)
     ap.add_argument("--option", action="append", default=[], help="name=value scanner option")
+    ap.add_argument("--merge-every", type=int, default=0,
+                    help="steps merged by one all-reduce (N > 1); 0 = one merge per job (all timed steps)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="collective backend for N > 1: nccl = RCCL over xGMI (default); gloo = "
                          "rehearsal of the multi-rank logic with several ranks on ONE GPU")
@@ -133,35 +137,55 @@ def main():
     tb.fill_synthetic(spec, lane_tile, list(range(L)))
     setup_s = time.time() - t0
 
-    # global counter block: every rank owns rows [rank*tiles, (rank+1)*tiles).  Two of them:
-    # the all-reduce of step i (RCCL runs it on its own stream) overlaps the scan of step i+1,
-    # which writes the other block.
-    blocks = [torch.zeros((world * args.tiles, ncnt), dtype=torch.int64, device="cuda") for _ in range(2)]
+    # The job's counter block: one [world*tiles, ncnt] slab per step (= per lane batch), every
+    # rank owning rows [rank*tiles, (rank+1)*tiles) of each slab.  As in the CLI
+    # (count_well_duplicates.py of this package: one merge per run) the ranks' rows are merged
+    # by ONE int64 all-reduce per job, i.e. per `--merge-every` steps (default: all K timed
+    # steps, at most 256 slabs = 41 MB at 8 GPUs); `--merge-every 1` merges after every step.
+    # Two job blocks alternate so that a merge (RCCL runs it on its own stream) overlaps the
+    # scans of the next chunk.
+    chunk = max(1, min(args.merge_every if args.merge_every > 0 else max(args.steps, 1), 256))
+    jobs = [torch.zeros((chunk, world * args.tiles, ncnt), dtype=torch.int64, device="cuda") for _ in range(2)]
     pending = [None, None]
-    step_no = [0]
+    turn = [0]
 
-    def step():
-        b = step_no[0] & 1
-        step_no[0] += 1
-        block = blocks[b]
-        my_rows = block[rank * args.tiles:(rank + 1) * args.tiles]
-        if use_dist:
-            if pending[b] is not None:
-                pending[b].wait()           # this block's previous all-reduce (two steps ago)
-            block.zero_()
-        sc.scan_async(tb.tables, args.tiles, L, n_clusters, mode, k, my_rows.data_ptr())
-        if use_dist and not rehearsal:
-            # RCCL int64 sum over xGMI; the ranks' rows are disjoint
-            pending[b] = dist.all_reduce(block, async_op=True)
-        elif use_dist:
-            host = block.cpu()
+    def merge(buf, used):
+        view = jobs[buf][:used]
+        if rehearsal:
+            host = view.cpu()
             dist.all_reduce(host)
-            block.copy_(host)
+            view.copy_(host)
+        else:
+            # RCCL int64 sum over xGMI; the ranks' rows are disjoint
+            pending[buf] = dist.all_reduce(view, async_op=True)
 
     def finish_collectives():
-        for w in pending:
+        for i, w in enumerate(pending):
             if w is not None:
                 w.wait()
+                pending[i] = None
+
+    def run(n_steps):
+        """n_steps scans, merged chunk by chunk; returns the slab of the last step."""
+        done, last = 0, None
+        while done < n_steps:
+            buf = turn[0]
+            turn[0] ^= 1
+            if pending[buf] is not None:
+                pending[buf].wait()             # this block's previous merge (two chunks ago)
+                pending[buf] = None
+            n = min(chunk, n_steps - done)
+            if use_dist:
+                jobs[buf][:n].zero_()           # the other ranks' rows (a scan clears its own)
+            for s_i in range(n):
+                rows = jobs[buf][s_i, rank * args.tiles:(rank + 1) * args.tiles]
+                sc.scan_async(tb.tables, args.tiles, L, n_clusters, mode, k, rows.data_ptr())
+            if use_dist:
+                merge(buf, n)
+            done += n
+            last = jobs[buf][n - 1]
+        finish_collectives()
+        return last
 
     def fence():
         torch.cuda.synchronize()
@@ -169,21 +193,19 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
-    finish_collectives()
+    run(args.warmup)
     sc.scan_status()
     fence()
     t_start = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    finish_collectives()
+    block = run(args.steps)
     fence()
     elapsed = time.perf_counter() - t_start
     sc.scan_status()
     elapsed = wdist.max_over_ranks(elapsed, world, device="cpu" if rehearsal else "cuda")   # slowest rank
 
-    block = blocks[(step_no[0] - 1) & 1]                       # the last step's (merged) block
+    if block is None:                                           # --steps 0
+        block = run(1)
+        fence()
     my_rows = block[rank * args.tiles:(rank + 1) * args.tiles]
     counts = block.cpu().numpy()
     compares_all = int(counts[:, 1:1 + levels].sum())          # sum of Wells over every rank
@@ -305,6 +327,7 @@ def main():
                        "mode": args.mode, "k": k, "early_exit": not args.no_early_exit,
                        "clusters_per_tile": n_clusters, "compares_per_step": compares_all,
                        "valid_targets_per_rank": valid_rank, "parallelism": "tiles sharded, %d rank(s)" % world,
+                       "merge": None if not use_dist else "one int64 all-reduce per %d step(s)" % chunk,
                        "setup_s": round(setup_s, 1)},
             "roofline": roofline,
             "cpu_baseline": cpu,
