@@ -389,7 +389,43 @@ def test_dense_all_centres_small(sc):
             assert (got == want).all(), (mode, k)
             assert (blocks_to_reference(blocks[i], levels) == oracle.tally_tile(valid, dups, lens)).all()
         assert blocks[:, 1 + levels:1 + 2 * levels].sum() > 0
+    # a survivor queue far too small: what does not fit is finished inside the pairs kernel
+    want = {}
+    for mode, k in ((0, 0), (1, 1)):
+        sc.set_option("dense_kernel", 1)
+        want[(mode, k)] = tb.count(mode, k, per_target=True)
+        sc.set_option("dense_queue_cap", 37)
+        blocks, pt = tb.count(mode, k, per_target=True)
+        sc.set_option("dense_queue_cap", 0)
+        sc.set_option("dense_kernel", -1)
+        assert (blocks == want[(mode, k)][0]).all() and (pt == want[(mode, k)][1]).all()
     tb.free()
+
+
+@pytest.mark.parametrize("L", [1, 3, 5, 6, 9])
+def test_dense_short_reads(sc, L):
+    """Reads no longer than the 5-cycle signature never reach the verify kernel; low diversity
+    (1-3 bases) makes nearly every neighbour a duplicate."""
+    rng = np.random.default_rng(L)
+    spec = synth.SynthSpec(seed=50 + L, n_clusters=5003, row=71, plant_per_64k=20000, nocall_per_64k=3000)
+    T, levels = 900, 3
+    centre, lvl_off, nbr = _random_case(rng, spec.n_clusters, T, levels, ring=9)
+    sc.set_targets(centre, lvl_off, nbr)
+    tb = TileBatch(sc, 1, L, spec.n_clusters)
+    tb.fill_synthetic(spec, [(1, 1101)], list(range(L)))
+    planes, filt, c2, n2, _ = compact_tile(spec, 1, 1101, list(range(L)), centre, nbr)
+    try:
+        for mode, k in ((0, 0), (1, 1), (1, 2)):
+            sc.set_option("dense_kernel", 1)
+            bl, pt = tb.count(mode, k, per_target=True)
+            valid, dups, lens, _ = oracle.count_tile(planes, filt, c2, lvl_off, n2, mode, k)
+            got = pt[0].astype(np.int64)
+            got[got == INVALID_TARGET] = -1
+            assert (got == np.where(valid[:, None] == 1, dups, -1)).all(), (L, mode, k)
+            assert (blocks_to_reference(bl[0], levels) == oracle.tally_tile(valid, dups, lens)).all()
+    finally:
+        sc.set_option("dense_kernel", -1)
+        tb.free()
 
 
 def test_less_travelled_paths(sc):

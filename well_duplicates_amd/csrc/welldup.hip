@@ -9,7 +9,7 @@
 //   synth_kernels.inc     device twin of the synthetic-data spec
 //   scan_sequential.inc   ScanArgs, HamState / LevState<H>, k_scan (Levenshtein, full gather)
 //   scan_queue.inc        survivor queue + k_scan_q: the default equality / Hamming kernel
-//   scan_dense.inc        k_scan_dense: one lane per target ("every well is a centre")
+//   scan_dense.inc        dense path: one lane per target ("every well is a centre")
 //   scan_lev_generic.inc  Levenshtein with any threshold (DP row in LDS)
 //   gen_rings.inc         neighbour-index generator (prepare_cluster_indexes.py on device)
 //   ingest_kernels.inc    gather of a few wells' bytes for the duplicate log
@@ -122,6 +122,18 @@ struct wd_ctx {
     int queue_kernel = 1;      // equality / Hamming with early exit: use k_scan_q
     int queue_first = 0;       // cycles of its first round; 0 = choose from k
     int dense_kernel = -1;     // lane-per-target kernel: -1 = when the targets look dense
+    int dense_tile_chunk = 4;  // dense kernel: tiles that share a target block's index lines in L2
+    uint16_t *d_sig = nullptr; // dense kernel: signature planes [n_tiles][sig_stride]
+    size_t sig_cap = 0;        // elements
+    unsigned long long *d_partial = nullptr;   // dense path: counter slots [n_tiles][kDenseSlots][stride]
+    size_t partial_cap = 0;    // elements
+    uint32_t *d_mask = nullptr;                // dense path: per-target hit masks, 4 targets per word
+    size_t mask_cap = 0;       // words
+    uint2 *d_queue = nullptr;                  // dense path: survivors of the signature round
+    size_t queue_cap = 0;      // entries
+    uint32_t *d_qcnt = nullptr;                // dense path: entries used per block region
+    size_t qcnt_cap = 0;
+    long long dense_queue_cap = 0;             // option: entries per 256-target block; 0 = from k
     int profile = 0;
 
     // targets (device)
@@ -343,6 +355,99 @@ void launch_queue_lev(wd_ctx *ctx, const ScanArgs &a, dim3 grid)
         hipLaunchKernelGGL((k_scan_q<STRIDED, lev_first(H), H>), grid, dim3(kBlock), lds, ctx->stream, a);
 }
 
+// grow-only device scratch of the dense path
+template <typename T>
+int dense_reserve(wd_ctx *ctx, T *&ptr, size_t &cap, size_t need, const char *what)
+{
+    if (need <= cap)
+        return WD_OK;
+    WD_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    (void)hipFree(ptr);
+    ptr = nullptr;
+    cap = 0;
+    if (hipMalloc((void **)&ptr, need * sizeof(T)) != hipSuccess)
+        return fail(ctx, WD_ERR_NOMEM, what);
+    cap = need;
+    return WD_OK;
+}
+
+// The dense path of wd_scan_async (scan_dense.inc): signatures, pairs, verify, reduce.
+int launch_dense(wd_ctx *ctx, const ScanArgs &a, dim3 grid, int n_tiles, int64_t N, bool strided,
+                 size_t n_plane_ptrs, int tile_chunk)
+{
+    int rc = ensure_dense_tables(ctx);
+    if (rc)
+        return rc;
+    DenseArgs d;
+    d.planes = a.planes;
+    d.filter = a.filter;
+    d.stride = a.stride;
+    d.centre = a.centre;
+    d.lvl_off = a.lvl_off;
+    d.nbr_t = ctx->d_nbr_t;
+    d.gbase = ctx->d_gbase;
+    d.out_per_target = a.out_per_target;
+    d.rare = a.rare;
+    d.N = N;
+    d.T = a.T;
+    d.levels = a.levels;
+    d.L = a.L;
+    d.k = a.k;
+    d.n_tiles = n_tiles;
+    d.tile_chunk = tile_chunk;
+    d.sig_cycles = std::min(kSigCycles, a.L);
+    d.strided = strided ? 1 : 0;
+    d.check_empty = a.check_empty;
+    d.log_hits = a.log_hits;
+    d.sig_stride = (N + 127) & ~(long long)127;
+    d.partial_stride = ((1 + 5 * a.levels) + 15) & ~15;              // whole 128-byte lines per slot
+    d.mask_stride = (((long long)a.T + 3) / 4 + 31) & ~31ll;
+    // survivors per block of 256 targets: 36 * P(<= k mismatches in 5 cycles) per target on
+    // diverse reads (9, 144, 950 for k = 0, 1, 2) plus one per duplicate pair; what does not fit
+    // a block's region is finished inside k_dense_pairs, so this is a speed knob, not a limit
+    const long long regions = (long long)n_tiles * ((a.T + kBlock - 1) / kBlock);
+    long long q_per = ctx->dense_queue_cap > 0 ? ctx->dense_queue_cap : (a.k <= 0 ? 64 : a.k == 1 ? 320 : 1536);
+    q_per = std::max<long long>(1, std::min<long long>(q_per, 7168));     // LDS: 8 bytes each
+    d.q_per = (int)q_per;
+    const size_t part_need = (size_t)n_tiles * kDenseSlots * d.partial_stride;
+    const size_t mask_need = (size_t)n_tiles * d.mask_stride;
+    if ((rc = dense_reserve(ctx, ctx->d_sig, ctx->sig_cap, (size_t)d.sig_stride * n_tiles, "signature planes")) ||
+        (rc = dense_reserve(ctx, ctx->d_partial, ctx->partial_cap, part_need, "counter slots")) ||
+        (rc = dense_reserve(ctx, ctx->d_mask, ctx->mask_cap, mask_need, "hit masks")) ||
+        (rc = dense_reserve(ctx, ctx->d_queue, ctx->queue_cap, (size_t)(regions * q_per), "survivor queue")) ||
+        (rc = dense_reserve(ctx, ctx->d_qcnt, ctx->qcnt_cap, (size_t)regions, "survivor counts")))
+        return rc;
+    d.sig = ctx->d_sig;
+    d.partial = ctx->d_partial;
+    d.mask = ctx->d_mask;
+    d.queue = ctx->d_queue;
+    d.q_cnt = ctx->d_qcnt;
+    WD_HIP(ctx, hipMemsetAsync(ctx->d_partial, 0, part_need * sizeof(unsigned long long), ctx->stream));
+    WD_HIP(ctx, hipMemsetAsync(ctx->d_mask, 0, mask_need * sizeof(uint32_t), ctx->stream));
+
+    // dword loads in k_dense_sig need every plane 4-byte aligned
+    bool aligned4 = (a.stride & 3) == 0;
+    for (size_t i = 0; i < n_plane_ptrs && aligned4; i++)
+        aligned4 = ((uintptr_t)ctx->h_tbl[i] & 3u) == 0;
+    if (aligned4) {
+        const dim3 sgrid((unsigned)((N + 4ll * kBlock - 1) / (4ll * kBlock)), (unsigned)n_tiles);
+        hipLaunchKernelGGL((k_dense_sig<true>), sgrid, dim3(kBlock), 0, ctx->stream, d);
+    } else {
+        const dim3 sgrid((unsigned)((N + kBlock - 1) / kBlock), (unsigned)n_tiles);
+        hipLaunchKernelGGL((k_dense_sig<false>), sgrid, dim3(kBlock), 0, ctx->stream, d);
+    }
+    const size_t q_lds = (size_t)d.q_per * sizeof(uint2);
+    if (a.k == 0)
+        hipLaunchKernelGGL((k_dense_pairs<true>), grid, dim3(kBlock), q_lds, ctx->stream, d);
+    else
+        hipLaunchKernelGGL((k_dense_pairs<false>), grid, dim3(kBlock), q_lds, ctx->stream, d);
+    hipLaunchKernelGGL(k_dense_verify, dim3((unsigned)((regions + kWaves - 1) / kWaves)), dim3(kBlock), 0,
+                           ctx->stream, d);
+    hipLaunchKernelGGL(k_dense_reduce, dim3(n_tiles), dim3(kWave), 0, ctx->stream, ctx->d_partial,
+                       d.partial_stride, 1 + 5 * a.levels, a.out_tile);
+    return WD_OK;
+}
+
 bool valid_batches(int b1, int b2)
 {
     for (auto &p : kHamShapes)
@@ -439,6 +544,11 @@ void wd_destroy(wd_ctx *ctx)
     (void)hipFree(ctx->d_status);
     (void)hipFree(ctx->d_rare);
     (void)hipFree(ctx->d_nbr_t);
+    (void)hipFree(ctx->d_sig);
+    (void)hipFree(ctx->d_partial);
+    (void)hipFree(ctx->d_mask);
+    (void)hipFree(ctx->d_queue);
+    (void)hipFree(ctx->d_qcnt);
     (void)hipFree(ctx->d_gbase);
     (void)hipHostFree(ctx->h_status);
     (void)hipFree(ctx->d_out_tile);
@@ -504,6 +614,14 @@ int wd_set_option(wd_ctx *ctx, const char *name, int64_t value)
         ctx->stream = value ? (hipStream_t) nullptr : ctx->own_stream;
     } else if (n == "dense_kernel") {
         ctx->dense_kernel = value < 0 ? -1 : (value ? 1 : 0);
+    } else if (n == "dense_tile_chunk") {
+        if (value < 1 || value > 1024)
+            return WD_ERR_ARG;
+        ctx->dense_tile_chunk = (int)value;
+    } else if (n == "dense_queue_cap") {
+        if (value < 0)
+            return WD_ERR_ARG;
+        ctx->dense_queue_cap = value;
     } else if (n == "queue_kernel") {
         ctx->queue_kernel = value ? 1 : 0;
     } else if (n == "queue_first") {
@@ -528,6 +646,8 @@ int wd_get_option(wd_ctx *ctx, const char *name, int64_t *value)
     else if (n == "profile") *value = ctx->profile;
     else if (n == "queue_kernel") *value = ctx->queue_kernel;
     else if (n == "dense_kernel") *value = ctx->dense_kernel;
+    else if (n == "dense_tile_chunk") *value = ctx->dense_tile_chunk;
+    else if (n == "dense_queue_cap") *value = ctx->dense_queue_cap;
     else if (n == "null_stream") *value = ctx->stream == nullptr ? 1 : 0;
     else if (n == "queue_first") *value = ctx->queue_first;
     else return fail(ctx, WD_ERR_ARG, "unknown option " + n);
@@ -753,8 +873,6 @@ int wd_scan_async(wd_ctx *ctx, int n_tiles, int L, int mode, int k, const uint8_
         }
     }
     a.rare = ctx->d_rare;
-    a.nbr_t = nullptr;
-    a.gbase = nullptr;
     a.log_hits = ctx->hit_cap > 0 ? 1 : 0;
     a.T = ctx->T;
     a.levels = levels;
@@ -773,8 +891,13 @@ int wd_scan_async(wd_ctx *ctx, int n_tiles, int L, int mode, int k, const uint8_
     const bool use_dense = dense_ok && (ctx->dense_kernel == 1 ||
                                         (ctx->dense_kernel < 0 && ctx->T >= 65536 && kk <= 1));
     const int chunks = (ctx->T + ctx->tpb - 1) / ctx->tpb;
+    const int tile_chunk = std::max(1, std::min(ctx->dense_tile_chunk, n_tiles));
+    // dense grid: 8 XCDs x (target blocks per XCD) x tile_chunk x (chunks of tiles), see k_dense_pairs
+    const long long dense_bpt = (ctx->T + kBlock - 1) / kBlock;
+    const long long dense_blocks = (long long)kXcds * ((dense_bpt + kXcds - 1) / kXcds) * tile_chunk *
+                                   ((n_tiles + tile_chunk - 1) / tile_chunk);
     const long long nblocks = lev_generic ? (long long)ctx->T * n_tiles
-                              : use_dense ? (long long)((ctx->T + kBlock - 1) / kBlock) * n_tiles
+                              : use_dense ? dense_blocks
                                           : (long long)chunks * n_tiles;
     if (nblocks > 0x7FFFFFFFll)
         return fail(ctx, WD_ERR_UNSUPPORTED, "grid too large; raise targets_per_block");
@@ -794,16 +917,9 @@ int wd_scan_async(wd_ctx *ctx, int n_tiles, int L, int mode, int k, const uint8_
     const bool use_queue = !lev && ctx->queue_kernel && ctx->early_exit && kk <= 254 &&
                            ctx->k_max <= (int64_t)kMaxPasses * kPass;
     if (use_dense) {
-        int rc = ensure_dense_tables(ctx);
+        int rc = launch_dense(ctx, a, grid, n_tiles, N, strided, n_plane_ptrs, tile_chunk);
         if (rc)
             return rc;
-        a.nbr_t = ctx->d_nbr_t;
-        a.gbase = ctx->d_gbase;
-        const size_t lds = (size_t)scan_dense_lds_dwords(levels) * sizeof(uint32_t);
-        if (strided)
-            hipLaunchKernelGGL((k_scan_dense<true>), grid, dim3(kBlock), lds, ctx->stream, a);
-        else
-            hipLaunchKernelGGL((k_scan_dense<false>), grid, dim3(kBlock), lds, ctx->stream, a);
     } else if (use_queue) {
         if (strided)
             launch_queue<true>(ctx, a, grid);
