@@ -80,7 +80,9 @@ int wd_synchronize(wd_ctx *ctx);
 /* Tunables, by name (default): "early_exit" (1), "targets_per_block" (64), "queue_kernel" (1),
  * "queue_first" (0 = from k), "batch_first" (4), "batch_next" (4), "profile" (0),
  * "null_stream" (0), "dense_kernel" (-1 = automatic: lane-per-target kernel when T >= 65536),
- * "dense_tile_chunk" (4: tiles that walk a block of targets together in the dense kernel).
+ * "dense_tile_chunk" (4: tiles that walk a block of targets together in the dense path),
+ * "dense_queue_cap" (0 = from k: survivor entries per 256 targets), "dense_pack" (-1 = pack all
+ * cycles into rows when the batch has many survivors, 0 = never, 1 = always).
  * Unknown names return WD_ERR_ARG. */
 int wd_set_option(wd_ctx *ctx, const char *name, int64_t value);
 int wd_get_option(wd_ctx *ctx, const char *name, int64_t *value);

@@ -15,7 +15,8 @@ from well_duplicates_amd.scanner import INVALID_TARGET, Scanner, TileBatch
 pytestmark = pytest.mark.gpu
 
 DEFAULT_OPTIONS = (("early_exit", 1), ("batch_first", 4), ("batch_next", 4), ("targets_per_block", 32),
-                   ("queue_kernel", 1), ("queue_first", 0), ("dense_kernel", -1))
+                   ("queue_kernel", 1), ("queue_first", 0), ("dense_kernel", -1), ("dense_pack", -1),
+                   ("dense_queue_cap", 0))
 
 
 @pytest.fixture(scope="module")
@@ -376,10 +377,13 @@ def test_dense_all_centres_small(sc):
     tb.fill_synthetic(spec, tiles, list(range(L)))
     host = [([synth.plane_bytes(spec, lane, tile, c) for c in range(L)],
              synth.filter_bytes(spec, lane, tile)) for lane, tile in tiles]
-    for mode, k, dense in ((0, 0, 1), (0, 0, 0), (1, 1, 1), (1, 2, 1), (1, 3, 1), (2, 2, 1)):
-        sc.set_option("dense_kernel", dense)      # lane-per-target kernel vs the queue kernel
+    for mode, k, dense, pack in ((0, 0, 1, 0), (0, 0, 1, 1), (0, 0, 0, -1), (1, 1, 1, 1), (1, 1, 1, 0),
+                                 (1, 2, 1, -1), (1, 2, 1, 1), (1, 3, 1, -1), (2, 2, 1, -1)):
+        sc.set_option("dense_kernel", dense)      # lane-per-target path vs the queue kernel
+        sc.set_option("dense_pack", pack)         # survivors checked on packed rows / on the planes
         blocks, pt = tb.count(mode, k, per_target=True)
         sc.set_option("dense_kernel", -1)
+        sc.set_option("dense_pack", -1)
         for i, (lane, tile) in enumerate(tiles):
             planes, filt = host[i]
             valid, dups, lens, _ = oracle.count_tile(planes, filt, centre, lvl_off, nbr, mode, k)

@@ -16,6 +16,7 @@ ap.add_argument("--tiles", type=int, default=2)
 ap.add_argument("--mode", type=int, default=0)
 ap.add_argument("-k", type=int, default=0)
 ap.add_argument("--chunk", default="4", help="comma list of dense_tile_chunk values to time")
+ap.add_argument("--pack", type=int, default=-1, help="dense_pack option: -1 auto, 0 never, 1 always")
 ap.add_argument("--plant", type=int, default=1311, help="planted wells per 65536 (1311 = 2 %%)")
 a = ap.parse_args()
 n = a.rows * a.cols
@@ -29,6 +30,7 @@ tb = TileBatch(sc, a.tiles, a.bases, n)
 tb.fill_synthetic(spec, [(1, 1101 + i) for i in range(a.tiles)], list(range(a.bases)))
 out = sc.malloc(a.tiles * (1 + 5 * a.levels) * 8)
 sc.set_option("profile", 1)
+sc.set_option("dense_pack", a.pack)
 for ch in [int(v) for v in a.chunk.split(",")] * 2:
     sc.set_option("dense_tile_chunk", ch)
     print("dense_tile_chunk", ch, end=": ")

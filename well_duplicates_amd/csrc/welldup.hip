@@ -123,7 +123,7 @@ struct wd_ctx {
     int queue_first = 0;       // cycles of its first round; 0 = choose from k
     int dense_kernel = -1;     // lane-per-target kernel: -1 = when the targets look dense
     int dense_tile_chunk = 4;  // dense kernel: tiles that share a target block's index lines in L2
-    uint16_t *d_sig = nullptr; // dense kernel: signature planes [n_tiles][sig_stride]
+    uint32_t *d_sig = nullptr; // dense path: signature planes [n_tiles][sig_stride]
     size_t sig_cap = 0;        // elements
     unsigned long long *d_partial = nullptr;   // dense path: counter slots [n_tiles][kDenseSlots][stride]
     size_t partial_cap = 0;    // elements
@@ -134,6 +134,10 @@ struct wd_ctx {
     uint32_t *d_qcnt = nullptr;                // dense path: entries used per block region
     size_t qcnt_cap = 0;
     long long dense_queue_cap = 0;             // option: entries per 256-target block; 0 = from k
+    uint32_t *d_cand = nullptr;                // dense path: survivor counts of the batch (kDenseSlots)
+    uint4 *d_rows = nullptr;                   // dense path: packed cycles [n_tiles][kRowGroups][N]
+    size_t rows_cap = 0;       // uint4 elements
+    int dense_pack = -1;                       // option: -1 = by survivor count, 0 = never, 1 = always
     int profile = 0;
 
     // targets (device)
@@ -417,6 +421,33 @@ int launch_dense(wd_ctx *ctx, const ScanArgs &a, dim3 grid, int n_tiles, int64_t
         (rc = dense_reserve(ctx, ctx->d_queue, ctx->queue_cap, (size_t)(regions * q_per), "survivor queue")) ||
         (rc = dense_reserve(ctx, ctx->d_qcnt, ctx->qcnt_cap, (size_t)regions, "survivor counts")))
         return rc;
+    if (!ctx->d_cand)
+        WD_HIP(ctx, hipMalloc((void **)&ctx->d_cand, kDenseSlots * sizeof(uint32_t)));
+    // packed rows are optional scratch (64 bytes per well): without them every survivor is
+    // checked against the planes
+    d.rows = nullptr;
+    d.pack_mode = ctx->dense_pack;
+    if (ctx->dense_pack != 0 && a.L > d.sig_cycles && a.L <= 40 * kRowGroups) {
+        const size_t rows_need = (size_t)n_tiles * (size_t)N * kRowGroups;
+        if (rows_need > ctx->rows_cap) {
+            WD_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            (void)hipFree(ctx->d_rows);
+            ctx->d_rows = nullptr;
+            ctx->rows_cap = 0;
+            if (hipMalloc((void **)&ctx->d_rows, rows_need * sizeof(uint4)) == hipSuccess)
+                ctx->rows_cap = rows_need;
+            else
+                (void)hipGetLastError();
+        }
+        d.rows = ctx->d_rows;
+    }
+    // Checking one survivor against the planes touches ~2 (L - 10) cache lines (measured: 2.7 ns
+    // per duplicate record at 150 bp, HBM line rate); packing streams every plane once and
+    // writes 64 bytes per well (measured: 0.2 ms per 4.3 M-well tile).  Break-even is at about
+    // one record per 8192 plane bytes.
+    d.pack_threshold = std::max<long long>(1, (long long)n_tiles * N * a.L / 8192);
+    d.cand = ctx->d_cand;
+    WD_HIP(ctx, hipMemsetAsync(ctx->d_cand, 0, kDenseSlots * sizeof(uint32_t), ctx->stream));
     d.sig = ctx->d_sig;
     d.partial = ctx->d_partial;
     d.mask = ctx->d_mask;
@@ -429,20 +460,38 @@ int launch_dense(wd_ctx *ctx, const ScanArgs &a, dim3 grid, int n_tiles, int64_t
     bool aligned4 = (a.stride & 3) == 0;
     for (size_t i = 0; i < n_plane_ptrs && aligned4; i++)
         aligned4 = ((uintptr_t)ctx->h_tbl[i] & 3u) == 0;
-    if (aligned4) {
-        const dim3 sgrid((unsigned)((N + 4ll * kBlock - 1) / (4ll * kBlock)), (unsigned)n_tiles);
-        hipLaunchKernelGGL((k_dense_sig<true>), sgrid, dim3(kBlock), 0, ctx->stream, d);
-    } else {
-        const dim3 sgrid((unsigned)((N + kBlock - 1) / kBlock), (unsigned)n_tiles);
-        hipLaunchKernelGGL((k_dense_sig<false>), sgrid, dim3(kBlock), 0, ctx->stream, d);
-    }
+    const dim3 grid4((unsigned)((N + 4ll * kBlock - 1) / (4ll * kBlock)), (unsigned)n_tiles);
+    const dim3 grid1((unsigned)((N + kBlock - 1) / kBlock), (unsigned)n_tiles);
+    if (aligned4 && strided)
+        hipLaunchKernelGGL((k_dense_sig<true, true>), grid4, dim3(kBlock), 0, ctx->stream, d);
+    else if (aligned4)
+        hipLaunchKernelGGL((k_dense_sig<true, false>), grid4, dim3(kBlock), 0, ctx->stream, d);
+    else if (strided)
+        hipLaunchKernelGGL((k_dense_sig<false, true>), grid1, dim3(kBlock), 0, ctx->stream, d);
+    else
+        hipLaunchKernelGGL((k_dense_sig<false, false>), grid1, dim3(kBlock), 0, ctx->stream, d);
     const size_t q_lds = (size_t)d.q_per * sizeof(uint2);
     if (a.k == 0)
         hipLaunchKernelGGL((k_dense_pairs<true>), grid, dim3(kBlock), q_lds, ctx->stream, d);
     else
         hipLaunchKernelGGL((k_dense_pairs<false>), grid, dim3(kBlock), q_lds, ctx->stream, d);
-    hipLaunchKernelGGL(k_dense_verify, dim3((unsigned)((regions + kWaves - 1) / kWaves)), dim3(kBlock), 0,
-                           ctx->stream, d);
+    if (d.rows) {
+        if (aligned4 && strided)
+            hipLaunchKernelGGL((k_dense_pack<4, true>), grid4, dim3(kBlock), 0, ctx->stream, d);
+        else if (aligned4)
+            hipLaunchKernelGGL((k_dense_pack<4, false>), grid4, dim3(kBlock), 0, ctx->stream, d);
+        else if (strided)
+            hipLaunchKernelGGL((k_dense_pack<1, true>), grid1, dim3(kBlock), 0, ctx->stream, d);
+        else
+            hipLaunchKernelGGL((k_dense_pack<1, false>), grid1, dim3(kBlock), 0, ctx->stream, d);
+    }
+    const unsigned bpt = (unsigned)((a.T + kBlock - 1) / kBlock);
+    const unsigned nvb = (bpt + kWaves - 1) / kWaves;
+    const dim3 vgrid(kXcds * ((nvb + kXcds - 1) / kXcds), (unsigned)n_tiles);
+    if (strided)
+        hipLaunchKernelGGL((k_dense_verify<true>), vgrid, dim3(kBlock), 0, ctx->stream, d);
+    else
+        hipLaunchKernelGGL((k_dense_verify<false>), vgrid, dim3(kBlock), 0, ctx->stream, d);
     hipLaunchKernelGGL(k_dense_reduce, dim3(n_tiles), dim3(kWave), 0, ctx->stream, ctx->d_partial,
                        d.partial_stride, 1 + 5 * a.levels, a.out_tile);
     return WD_OK;
@@ -549,6 +598,8 @@ void wd_destroy(wd_ctx *ctx)
     (void)hipFree(ctx->d_mask);
     (void)hipFree(ctx->d_queue);
     (void)hipFree(ctx->d_qcnt);
+    (void)hipFree(ctx->d_cand);
+    (void)hipFree(ctx->d_rows);
     (void)hipFree(ctx->d_gbase);
     (void)hipHostFree(ctx->h_status);
     (void)hipFree(ctx->d_out_tile);
@@ -618,6 +669,8 @@ int wd_set_option(wd_ctx *ctx, const char *name, int64_t value)
         if (value < 1 || value > 1024)
             return WD_ERR_ARG;
         ctx->dense_tile_chunk = (int)value;
+    } else if (n == "dense_pack") {
+        ctx->dense_pack = value < 0 ? -1 : (value ? 1 : 0);
     } else if (n == "dense_queue_cap") {
         if (value < 0)
             return WD_ERR_ARG;
@@ -648,6 +701,7 @@ int wd_get_option(wd_ctx *ctx, const char *name, int64_t *value)
     else if (n == "dense_kernel") *value = ctx->dense_kernel;
     else if (n == "dense_tile_chunk") *value = ctx->dense_tile_chunk;
     else if (n == "dense_queue_cap") *value = ctx->dense_queue_cap;
+    else if (n == "dense_pack") *value = ctx->dense_pack;
     else if (n == "null_stream") *value = ctx->stream == nullptr ? 1 : 0;
     else if (n == "queue_first") *value = ctx->queue_first;
     else return fail(ctx, WD_ERR_ARG, "unknown option " + n);
