@@ -432,6 +432,44 @@ def test_dense_short_reads(sc, L):
         tb.free()
 
 
+def test_dense_far_neighbours(sc):
+    """Neighbours further than +-32767 wells from their centre: the dense path's index table falls
+    back from int16 offsets to int32 indices."""
+    rng = np.random.default_rng(5)
+    n, T, levels, L = 200003, 700, 3, 24
+    spec = synth.SynthSpec(seed=77, n_clusters=n, row=449, plant_per_64k=0, nocall_per_64k=2000)
+    centre = rng.choice(n, size=T, replace=False).astype(np.int32)
+    sizes = rng.integers(1, 7, size=(T, levels))
+    lvl_off = np.zeros((T, levels + 1), np.int32)
+    lvl_off[:, 1:] = np.cumsum(sizes, axis=1)
+    lvl_off += np.concatenate([[0], np.cumsum(sizes.sum(axis=1))[:-1]]).astype(np.int32)[:, None]
+    nbr = rng.integers(0, n, size=int(sizes.sum())).astype(np.int32)
+    assert np.abs(nbr.astype(np.int64) - np.repeat(centre, sizes.sum(axis=1))).max() > 40000
+    sc.set_targets(centre, lvl_off, nbr)
+    tb = TileBatch(sc, 1, L, n)
+    tb.fill_synthetic(spec, [(1, 1101)], list(range(L)))
+    # make some far pairs identical: copy the centre's bytes over its first neighbour
+    planes = [tb.download_plane(0, c) for c in range(L)]
+    first = nbr[lvl_off[::3, 0]]
+    for c in range(L):
+        planes[c][first] = planes[c][centre[::3]]
+        sc.h2d(tb.plane_ptr(0, c), planes[c])
+    filt = tb.download_filter(0)
+    try:
+        for mode, k in ((0, 0), (1, 1)):
+            sc.set_option("dense_kernel", 1)
+            bl, pt = tb.count(mode, k, per_target=True)
+            valid, dups, lens, _ = oracle.count_tile(planes, filt, centre, lvl_off, nbr, mode, k)
+            got = pt[0].astype(np.int64)
+            got[got == INVALID_TARGET] = -1
+            assert (got == np.where(valid[:, None] == 1, dups, -1)).all()
+            assert (blocks_to_reference(bl[0], levels) == oracle.tally_tile(valid, dups, lens)).all()
+            assert dups[valid == 1].sum() >= (valid[::3] == 1).sum() > 0
+    finally:
+        sc.set_option("dense_kernel", -1)
+        tb.free()
+
+
 def test_less_travelled_paths(sc):
     """Pointer-table plane layout x {dense kernel, generic Levenshtein}, their hit logs, empty
     rings under the dense kernel, and scans without the per-target output."""

@@ -147,7 +147,9 @@ struct wd_ctx {
     int64_t idx_min = 0, idx_max = -1;
     int64_t k_max = 0;         // most neighbour slots of any target
     std::vector<long long> h_gbase;   // per 64-target group: start in the transposed table
-    int32_t *d_nbr_t = nullptr;       // built on first use of the dense kernel
+    void *d_nbr_t = nullptr;          // built on first use of the dense path: int16 offsets or int32 indices
+    bool nbr_t16 = false;
+    int32_t *d_rel_t = nullptr;       // dense path: ring ends per target, level-major
     long long *d_gbase = nullptr;
     bool has_targets = false;
     bool has_empty_level = false;
@@ -325,8 +327,10 @@ void set_group_bases(wd_ctx *ctx, const int32_t *lvl_off, int T, int levels)
     ctx->h_gbase[groups] = pos;
     (void)hipFree(ctx->d_nbr_t);
     (void)hipFree(ctx->d_gbase);
+    (void)hipFree(ctx->d_rel_t);
     ctx->d_nbr_t = nullptr;
     ctx->d_gbase = nullptr;
+    ctx->d_rel_t = nullptr;
 }
 
 // Build the device copy of the transposed table (first dense scan after new targets).
@@ -337,12 +341,35 @@ int ensure_dense_tables(wd_ctx *ctx)
     const int groups = (ctx->T + kWave - 1) / kWave;
     const long long total = ctx->h_gbase.empty() ? 0 : ctx->h_gbase.back();
     WD_HIP(ctx, hipMalloc((void **)&ctx->d_gbase, (size_t)(groups + 1) * sizeof(long long)));
-    WD_HIP(ctx, hipMalloc((void **)&ctx->d_nbr_t, std::max<long long>(1, total) * sizeof(int32_t)));
     WD_HIP(ctx, hipMemcpyAsync(ctx->d_gbase, ctx->h_gbase.data(), (size_t)(groups + 1) * sizeof(long long),
                                hipMemcpyHostToDevice, ctx->stream));
-    if (groups > 0)
-        hipLaunchKernelGGL(k_transpose_nbr, dim3(groups), dim3(kWave), 0, ctx->stream, ctx->d_centre,
-                           ctx->d_lvl_off, ctx->d_nbr, ctx->d_gbase, ctx->d_nbr_t, ctx->T, ctx->levels);
+    WD_HIP(ctx, hipMalloc((void **)&ctx->d_rel_t, std::max<size_t>(1, (size_t)ctx->T * ctx->levels) * sizeof(int32_t)));
+    if (ctx->T > 0)
+        hipLaunchKernelGGL(k_transpose_off, dim3((ctx->T + kBlock - 1) / kBlock), dim3(kBlock), 0, ctx->stream,
+                           ctx->d_lvl_off, ctx->d_rel_t, ctx->T, ctx->levels);
+    // int16 offsets from the centre if they all fit (half the index stream), else int32 indices
+    const size_t n_el = (size_t)std::max<long long>(1, total);
+    WD_HIP(ctx, hipMalloc(&ctx->d_nbr_t, n_el * sizeof(int16_t)));
+    ctx->nbr_t16 = true;
+    if (groups > 0) {
+        WD_HIP(ctx, hipMemsetAsync(ctx->d_status, 0, sizeof(uint32_t), ctx->stream));
+        hipLaunchKernelGGL((k_transpose_nbr<int16_t>), dim3(groups), dim3(kWave), 0, ctx->stream, ctx->d_centre,
+                           ctx->d_lvl_off, ctx->d_nbr, ctx->d_gbase, (int16_t *)ctx->d_nbr_t, ctx->T, ctx->levels,
+                           ctx->d_status);
+        uint32_t wide = 0;
+        WD_HIP(ctx, hipMemcpyAsync(&wide, ctx->d_status, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+        WD_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        WD_HIP(ctx, hipMemsetAsync(ctx->d_status, 0, sizeof(uint32_t), ctx->stream));
+        if (wide) {
+            (void)hipFree(ctx->d_nbr_t);
+            ctx->d_nbr_t = nullptr;
+            ctx->nbr_t16 = false;
+            WD_HIP(ctx, hipMalloc(&ctx->d_nbr_t, n_el * sizeof(int32_t)));
+            hipLaunchKernelGGL((k_transpose_nbr<int32_t>), dim3(groups), dim3(kWave), 0, ctx->stream, ctx->d_centre,
+                               ctx->d_lvl_off, ctx->d_nbr, ctx->d_gbase, (int32_t *)ctx->d_nbr_t, ctx->T,
+                               ctx->levels, ctx->d_status);
+        }
+    }
     WD_HIP(ctx, hipGetLastError());
     WD_HIP(ctx, hipStreamSynchronize(ctx->stream));       // h_gbase may be reused by the caller
     return WD_OK;
@@ -389,6 +416,8 @@ int launch_dense(wd_ctx *ctx, const ScanArgs &a, dim3 grid, int n_tiles, int64_t
     d.centre = a.centre;
     d.lvl_off = a.lvl_off;
     d.nbr_t = ctx->d_nbr_t;
+    d.idx16 = ctx->nbr_t16 ? 1 : 0;
+    d.rel_t = ctx->d_rel_t;
     d.gbase = ctx->d_gbase;
     d.out_per_target = a.out_per_target;
     d.rare = a.rare;
@@ -471,10 +500,14 @@ int launch_dense(wd_ctx *ctx, const ScanArgs &a, dim3 grid, int n_tiles, int64_t
     else
         hipLaunchKernelGGL((k_dense_sig<false, false>), grid1, dim3(kBlock), 0, ctx->stream, d);
     const size_t q_lds = (size_t)d.q_per * sizeof(uint2);
-    if (a.k == 0)
-        hipLaunchKernelGGL((k_dense_pairs<true>), grid, dim3(kBlock), q_lds, ctx->stream, d);
+    if (a.k == 0 && ctx->nbr_t16)
+        hipLaunchKernelGGL((k_dense_pairs<true, true>), grid, dim3(kBlock), q_lds, ctx->stream, d);
+    else if (a.k == 0)
+        hipLaunchKernelGGL((k_dense_pairs<true, false>), grid, dim3(kBlock), q_lds, ctx->stream, d);
+    else if (ctx->nbr_t16)
+        hipLaunchKernelGGL((k_dense_pairs<false, true>), grid, dim3(kBlock), q_lds, ctx->stream, d);
     else
-        hipLaunchKernelGGL((k_dense_pairs<false>), grid, dim3(kBlock), q_lds, ctx->stream, d);
+        hipLaunchKernelGGL((k_dense_pairs<false, false>), grid, dim3(kBlock), q_lds, ctx->stream, d);
     if (d.rows) {
         if (aligned4 && strided)
             hipLaunchKernelGGL((k_dense_pack<4, true>), grid4, dim3(kBlock), 0, ctx->stream, d);
@@ -593,6 +626,7 @@ void wd_destroy(wd_ctx *ctx)
     (void)hipFree(ctx->d_status);
     (void)hipFree(ctx->d_rare);
     (void)hipFree(ctx->d_nbr_t);
+    (void)hipFree(ctx->d_rel_t);
     (void)hipFree(ctx->d_sig);
     (void)hipFree(ctx->d_partial);
     (void)hipFree(ctx->d_mask);
