@@ -439,7 +439,7 @@ int launch_dense(wd_ctx *ctx, const ScanArgs &a, dim3 grid, int n_tiles, int64_t
     // diverse reads (9, 144, 950 for k = 0, 1, 2) plus one per duplicate pair; what does not fit
     // a block's region is finished inside k_dense_pairs, so this is a speed knob, not a limit
     const long long regions = (long long)n_tiles * ((a.T + kBlock - 1) / kBlock);
-    long long q_per = ctx->dense_queue_cap > 0 ? ctx->dense_queue_cap : (a.k <= 0 ? 64 : a.k == 1 ? 320 : 1536);
+    long long q_per = ctx->dense_queue_cap > 0 ? ctx->dense_queue_cap : (a.k <= 0 ? 128 : a.k == 1 ? 384 : 1536);
     q_per = std::max<long long>(1, std::min<long long>(q_per, 7168));     // LDS: 8 bytes each
     d.q_per = (int)q_per;
     const size_t part_need = (size_t)n_tiles * kDenseSlots * d.partial_stride;
