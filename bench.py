@@ -57,6 +57,9 @@ def parse():
     ap.add_argument("--cpu-tiles", type=int, default=8, help="tiles in the CPU-baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-steps", type=int, default=20)
+    ap.add_argument("--dense-tiles", type=int, default=4,
+                    help="tiles of the all-centres probe (BASELINE configs[4] shape: every well a centre, "
+                         "3 levels, 150 bp) reported under other_modes; 0 = skip")
     ap.add_argument("--option", action="append", default=[], help="name=value scanner option")
     ap.add_argument("--merge-every", type=int, default=0,
                     help="steps merged by one all-reduce (N > 1); 0 = one merge per job (all timed steps)")
@@ -64,6 +67,46 @@ def parse():
                     help="collective backend for N > 1: nccl = RCCL over xGMI (default); gloo = "
                          "rehearsal of the multi-rank logic with several ranks on ONE GPU")
     return ap.parse_args()
+
+
+def dense_probe(device, n_tiles, rows, cols, levels=3, bases=150):
+    """Kernel time of the dense path (scan_dense.inc) on n_tiles full-size tiles."""
+    import numpy as np
+    from well_duplicates_amd import synth
+    from well_duplicates_amd.scanner import Scanner, TileBatch, MODE_EQ
+    n = rows * cols
+    x, y = synth.honeycomb_pixels(rows, cols)
+    sc = Scanner(device)
+    try:
+        t0 = time.perf_counter()
+        T, P = sc.targets_from_coords(x, y, None, levels=levels)
+        gen_s = time.perf_counter() - t0
+        spec = synth.SynthSpec(seed=5, n_clusters=n, row=cols)
+        tb = TileBatch(sc, n_tiles, bases, n)
+        tb.fill_synthetic(spec, [(1, 1101 + i) for i in range(n_tiles)], list(range(bases)))
+        ncnt = 1 + 5 * levels
+        out = sc.malloc(n_tiles * ncnt * 8)
+        sc.scan_async(tb.tables, n_tiles, bases, n, MODE_EQ, 0, out)      # builds the tables
+        sc.set_option("profile", 1)
+        sc.profile_reset()
+        for _ in range(3):
+            sc.scan_async(tb.tables, n_tiles, bases, n, MODE_EQ, 0, out)
+        ms, launches = sc.profile_get()
+        ms /= max(1, launches)
+        blk = sc.d2h(out, n_tiles * ncnt * 8, np.int64).reshape(n_tiles, ncnt)
+        compares = int(blk[:, 1:1 + levels].sum())
+        b_dense = n_tiles * (n * bases + 4 * n * (1 + P / T) + n)             # SURVEY.md 8d, dense form
+        res = {"workload": "%d tiles x %d centres x %.1f neighbours, %d levels, %d bp, 2 %% planted"
+                           % (n_tiles, T, P / T, levels, bases),
+               "kernel_ms": round(ms, 4), "ms_per_tile": round(ms / n_tiles, 4),
+               "compares_per_s": round(compares / (ms * 1e-3), 1),
+               "duplicates_found": int(blk[:, 1 + levels:1 + 2 * levels].sum()),
+               "algorithmic_bytes": int(b_dense), "frac_of_hbm_peak": round(b_dense / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+               "ring_generator_s": round(gen_s, 3)}
+        tb.free()
+        return res
+    finally:
+        sc.close()
 
 
 def main():
@@ -249,6 +292,10 @@ def main():
         sc.scan_async(tb.tables, args.tiles, L, n_clusters, mode, k, my_rows.data_ptr())   # restore counters
         sc.scan_status()
     sc.set_option("profile", 0)
+    # BASELINE configs[4] in small: every well of a tile is a centre (device-generated rings,
+    # 3 levels), 150 bp, 2 % planted duplicates as in SURVEY.md 8d; its own context and planes
+    if rank == 0 and world == 1 and args.dense_tiles > 0 and args.profile_steps > 0 and args.mode == "eq":
+        other["dense_all_centres"] = dense_probe(local_rank, args.dense_tiles, rows, cols)
     b_alg = compares_rank * (L + 4) + valid_rank * (L + 5) + 8 * ncnt * args.tiles
     achieved = b_alg / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0
     traffic = None

@@ -490,8 +490,10 @@ def test_less_travelled_paths(sc):
             sc.h2d(ptrs[i][c], tb.download_plane(i, c))
     host = [compact_tile(spec, lane, tile, list(range(L)), centre, nbr) for lane, tile in tiles]
     try:
-        for mode, k, dense in ((0, 0, 1), (1, 1, 1), (2, 20, -1), (2, 25, -1)):
+        for mode, k, dense, pack in ((0, 0, 1, 0), (0, 0, 1, 1), (1, 1, 1, 1), (1, 1, 1, 0), (2, 20, -1, -1),
+                                     (2, 25, -1, -1)):
             sc.set_option("dense_kernel", dense)
+            sc.set_option("dense_pack", pack)
             sc.hitlog_enable(200000)
             bl, pt = sc.count_tiles(ptrs, tb.filter_ptrs(), n, mode, k, per_target=True)
             hits, total = sc.hitlog_fetch(200000)
@@ -528,6 +530,7 @@ def test_less_travelled_paths(sc):
             tb.count(0, 0)
     finally:
         sc.set_option("dense_kernel", -1)
+        sc.set_option("dense_pack", -1)
         sc.free(slab)
         tb.free()
 
