@@ -82,7 +82,9 @@ int wd_synchronize(wd_ctx *ctx);
  * "null_stream" (0), "dense_kernel" (-1 = automatic: lane-per-target kernel when T >= 65536),
  * "dense_tile_chunk" (4: tiles that walk a block of targets together in the dense path),
  * "dense_queue_cap" (0 = from k: survivor entries per 256 targets), "dense_pack" (-1 = pack all
- * cycles into rows when the batch has many survivors, 0 = never, 1 = always).
+ * cycles into rows when the batch has many survivors, 0 = never, 1 = always), "fast_inflate" (1:
+ * the loaders try the library's own gunzip before zlib; the environment variable WD_FAST_INFLATE
+ * sets the default).
  * Unknown names return WD_ERR_ARG. */
 int wd_set_option(wd_ctx *ctx, const char *name, int64_t value);
 int wd_get_option(wd_ctx *ctx, const char *name, int64_t *value);
@@ -187,6 +189,13 @@ int wd_scan_status(wd_ctx *ctx);
  */
 int wd_load_bcl_gz(wd_ctx *ctx, const char *path, uint8_t *dst_dev, int64_t n_clusters);
 int wd_load_filter(wd_ctx *ctx, const char *path, uint8_t *dst_dev, int64_t n_clusters);
+/* The host-side gunzip behind the two loaders, exposed for testing and reuse; no GPU involved.
+ * All members of a gzip file src[0, src_len) -> dst (at most dst_cap bytes), *produced = bytes
+ * written.  mode 0: zlib.  mode 1: the library's own RFC 1951/1952 decoder (CRC-32 and length of
+ * every member checked); it declines - WD_ERR_UNSUPPORTED - whatever it does not like, and the
+ * loaders then decode the file with zlib.  WD_ERR_IO: corrupt, truncated or longer than dst_cap. */
+int wd_gunzip(const uint8_t *src, size_t src_len, uint8_t *dst, size_t dst_cap, size_t *produced, int mode);
+
 /* NovaSeq: one tile's block of a `L00<lane>_<surface>.cbcl` file -> an n_clusters-byte plane on
  * the device, replacing _get_seqs_from_cbcl (bcl_direct_reader.py:255-325): header and tile
  * table checks (:263-295, WD_ERR_FORMAT), gunzip of the tile's block (:300-301), nibble

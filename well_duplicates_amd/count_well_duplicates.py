@@ -88,7 +88,7 @@ def parse_args(argv=None):
                    help="collective backend under torchrun (nccl = RCCL; gloo = CPU, for rehearsals)")
     p.add_argument("--tile-batch", type=int, default=32,
                    help="tiles kept resident in HBM and scanned per launch")
-    p.add_argument("--threads", type=int, default=min(16, os.cpu_count() or 1),
+    p.add_argument("--threads", type=int, default=min(32, os.cpu_count() or 1),
                    help="reader threads (gunzip)")
     p.add_argument("-o", "--output", default=None,
                    help="write the report to this file instead of stdout")

@@ -138,6 +138,7 @@ struct wd_ctx {
     uint4 *d_rows = nullptr;                   // dense path: packed cycles [n_tiles][kRowGroups][N]
     size_t rows_cap = 0;       // uint4 elements
     int dense_pack = -1;                       // option: -1 = by survivor count, 0 = never, 1 = always
+    int fast_inflate = 1;                      // option: own gunzip first, zlib as referee (0 = zlib only)
     int profile = 0;
 
     // targets (device)
@@ -189,6 +190,8 @@ struct wd_ctx {
         size_t cap = 0;
         uint8_t *dev = nullptr;        // device scratch (packed CBCL block + chunk sums)
         size_t dev_cap = 0;
+        uint8_t *file = nullptr;       // the compressed file, kept between calls (no mmap churn)
+        size_t file_cap = 0;
         hipStream_t stream = nullptr;
         bool busy = false;
     };
@@ -589,6 +592,8 @@ wd_ctx *wd_create(int device_id)
     }
     wd_ctx *ctx = new wd_ctx();
     ctx->device = device_id;
+    if (const char *fi = getenv("WD_FAST_INFLATE"))         // default of the "fast_inflate" option
+        ctx->fast_inflate = atoi(fi) ? 1 : 0;
     if (hipSetDevice(device_id) != hipSuccess ||
         hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking) != hipSuccess ||
         hipMalloc((void **)&ctx->d_status, sizeof(uint32_t)) != hipSuccess ||
@@ -643,6 +648,7 @@ void wd_destroy(wd_ctx *ctx)
     for (auto *sl : ctx->ingest_slots) {
         (void)hipHostFree(sl->pinned);
         (void)hipFree(sl->dev);
+        free(sl->file);
         if (sl->stream)
             (void)hipStreamDestroy(sl->stream);
         delete sl;
@@ -703,6 +709,8 @@ int wd_set_option(wd_ctx *ctx, const char *name, int64_t value)
         if (value < 1 || value > 1024)
             return WD_ERR_ARG;
         ctx->dense_tile_chunk = (int)value;
+    } else if (n == "fast_inflate") {
+        ctx->fast_inflate = value ? 1 : 0;
     } else if (n == "dense_pack") {
         ctx->dense_pack = value < 0 ? -1 : (value ? 1 : 0);
     } else if (n == "dense_queue_cap") {
@@ -736,6 +744,7 @@ int wd_get_option(wd_ctx *ctx, const char *name, int64_t *value)
     else if (n == "dense_tile_chunk") *value = ctx->dense_tile_chunk;
     else if (n == "dense_queue_cap") *value = ctx->dense_queue_cap;
     else if (n == "dense_pack") *value = ctx->dense_pack;
+    else if (n == "fast_inflate") *value = ctx->fast_inflate;
     else if (n == "null_stream") *value = ctx->stream == nullptr ? 1 : 0;
     else if (n == "queue_first") *value = ctx->queue_first;
     else return fail(ctx, WD_ERR_ARG, "unknown option " + n);
@@ -1369,6 +1378,38 @@ bool slurp(const char *path, std::vector<uint8_t> &buf)
     return ok;
 }
 
+// whole file -> the slot's own buffer (grow-only; 16 zero bytes follow the data, as fast_gunzip
+// wants).  A fresh multi-megabyte vector per call means an mmap, its page faults and a munmap
+// per file, and many loader threads then queue up on the process's memory-map lock.
+bool slurp_into(const char *path, uint8_t *&buf, size_t &cap, size_t *len)
+{
+    FILE *f = fopen(path, "rb");
+    if (!f)
+        return false;
+    bool ok = fseek(f, 0, SEEK_END) == 0;
+    long n = ok ? ftell(f) : -1;
+    ok = ok && n >= 0 && fseek(f, 0, SEEK_SET) == 0;
+    if (ok && (size_t)n + 16 > cap) {
+        free(buf);
+        cap = (size_t)n + 16 + ((size_t)n >> 3);
+        buf = (uint8_t *)malloc(cap);
+        if (!buf) {
+            cap = 0;
+            ok = false;
+        }
+    }
+    if (ok) {
+        ok = n == 0 || fread(buf, 1, (size_t)n, f) == (size_t)n;
+        memset(buf + n, 0, 16);
+        *len = (size_t)n;
+    }
+    fclose(f);
+    return ok;
+}
+
+constexpr size_t kInflateSlack = 274 + 320;   // room fast_gunzip may ask for beyond the data
+#include "fast_inflate.inc"
+
 int slot_reserve(wd_ctx::IngestSlot *s, size_t need)
 {
     if (!s->stream && hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking) != hipSuccess)
@@ -1386,6 +1427,53 @@ int slot_reserve(wd_ctx::IngestSlot *s, size_t need)
 
 }  // namespace
 
+int wd_gunzip(const uint8_t *src, size_t src_len, uint8_t *dst, size_t dst_cap, size_t *produced, int mode)
+{
+    if (!src || !dst || !produced || (mode != 0 && mode != 1))
+        return WD_ERR_ARG;
+    *produced = 0;
+    if (mode == 1) {
+        std::vector<uint8_t> in(src_len + 16, 0), out(dst_cap + kInflateSlack);
+        memcpy(in.data(), src, src_len);
+        size_t n = 0;
+        if (!fast_gunzip(in.data(), src_len, out.data(), dst_cap + 274, &n) || n > dst_cap)
+            return WD_ERR_UNSUPPORTED;                     // the loaders would turn to zlib here
+        memcpy(dst, out.data(), n);
+        *produced = n;
+        return WD_OK;
+    }
+    z_stream zs;
+    memset(&zs, 0, sizeof(zs));
+    if (src_len > 0xFFFFFFFFu || dst_cap > 0x7FFFFFFFu)
+        return WD_ERR_ARG;
+    if (inflateInit2(&zs, 16 + MAX_WBITS) != Z_OK)
+        return WD_ERR_NOMEM;
+    zs.next_in = const_cast<Bytef *>(src);
+    zs.avail_in = (uInt)src_len;
+    zs.next_out = dst;
+    zs.avail_out = (uInt)dst_cap;
+    int rc = WD_OK;
+    for (;;) {
+        const int zr = inflate(&zs, Z_NO_FLUSH);
+        if (zr == Z_STREAM_END) {
+            if (zs.avail_in == 0)
+                break;
+            if (inflateReset(&zs) != Z_OK) {
+                rc = WD_ERR_IO;
+                break;
+            }
+            continue;
+        }
+        if (zr != Z_OK || zs.avail_out == 0 || zs.avail_in == 0) {
+            rc = WD_ERR_IO;                                 // corrupt, too long for dst, or truncated
+            break;
+        }
+    }
+    *produced = (size_t)(zs.next_out - dst);
+    inflateEnd(&zs);
+    return rc;
+}
+
 // These two may be called from several host threads at once on one context (each call leases
 // its own pinned buffer and copy stream); they do not touch the context's error string.
 int wd_load_bcl_gz(wd_ctx *ctx, const char *path, uint8_t *dst_dev, int64_t n_clusters)
@@ -1394,43 +1482,49 @@ int wd_load_bcl_gz(wd_ctx *ctx, const char *path, uint8_t *dst_dev, int64_t n_cl
         return WD_ERR_ARG;
     if (hipSetDevice(ctx->device) != hipSuccess)
         return WD_ERR_HIP;
-    std::vector<uint8_t> raw;
-    if (!slurp(path, raw))
-        return WD_ERR_IO;                                  // FileNotFoundError in the reference
     SlotLease lease(ctx);
+    size_t raw_len = 0;
+    if (!slurp_into(path, lease.slot->file, lease.slot->file_cap, &raw_len))
+        return WD_ERR_IO;                                  // FileNotFoundError in the reference
+    const uint8_t *raw = lease.slot->file;
     const size_t want = (size_t)n_clusters + 4;
-    int rc = slot_reserve(lease.slot, want + 64);
+    int rc = slot_reserve(lease.slot, want + 64 + kInflateSlack);
     if (rc)
         return rc;
-    // gunzip (possibly several concatenated members) straight into the pinned buffer
-    z_stream zs;
-    memset(&zs, 0, sizeof(zs));
-    if (inflateInit2(&zs, 16 + MAX_WBITS) != Z_OK)
-        return WD_ERR_NOMEM;
-    zs.next_in = raw.data();
-    zs.avail_in = (uInt)std::min<size_t>(raw.size(), 0xFFFFFFFFu);
     size_t produced = 0;
-    bool bad = raw.size() > 0xFFFFFFFFu;
-    while (!bad) {
-        zs.next_out = lease.slot->pinned + produced;
-        zs.avail_out = (uInt)std::min<size_t>(want + 64 - produced, 0x7FFFFFFFu);
-        const int zr = inflate(&zs, Z_NO_FLUSH);
-        produced = (size_t)(zs.next_out - lease.slot->pinned);
-        if (zr == Z_STREAM_END) {
-            if (zs.avail_in == 0)
+    bool bad = false;
+    if (!ctx->fast_inflate ||
+        !fast_gunzip(raw, raw_len, lease.slot->pinned, want + 64 + 274, &produced) || produced > want + 64) {
+        // zlib: gunzip (possibly several concatenated members) straight into the pinned buffer
+        z_stream zs;
+        memset(&zs, 0, sizeof(zs));
+        if (inflateInit2(&zs, 16 + MAX_WBITS) != Z_OK)
+            return WD_ERR_NOMEM;
+        zs.next_in = const_cast<Bytef *>(raw);
+        zs.avail_in = (uInt)std::min<size_t>(raw_len, 0xFFFFFFFFu);
+        produced = 0;
+        bad = raw_len > 0xFFFFFFFFu;
+        while (!bad) {
+            zs.next_out = lease.slot->pinned + produced;
+            zs.avail_out = (uInt)std::min<size_t>(want + 64 - produced, 0x7FFFFFFFu);
+            const int zr = inflate(&zs, Z_NO_FLUSH);
+            produced = (size_t)(zs.next_out - lease.slot->pinned);
+            if (zr == Z_STREAM_END) {
+                if (zs.avail_in == 0)
+                    break;
+                if (inflateReset(&zs) != Z_OK)
+                    bad = true;
+                continue;
+            }
+            if (zr != Z_OK || zs.avail_out == 0) {
+                bad = zr != Z_OK;                          // avail_out == 0: more data than a plane
                 break;
-            if (inflateReset(&zs) != Z_OK)
-                bad = true;
-            continue;
+            }
+            if (zs.avail_in == 0)
+                break;                                     // truncated stream
         }
-        if (zr != Z_OK || zs.avail_out == 0) {
-            bad = zr != Z_OK;                              // avail_out == 0: more data than a plane
-            break;
-        }
-        if (zs.avail_in == 0)
-            break;                                         // truncated stream
+        inflateEnd(&zs);
     }
-    inflateEnd(&zs);
     if (bad)
         return WD_ERR_IO;
     if (produced < 4)
@@ -1527,29 +1621,33 @@ int wd_load_cbcl_tile(wd_ctx *ctx, const char *path, int tile_number, const uint
     }
     if (!found)
         return bail(WD_ERR_FORMAT);                          // assert t_number == tile_as_int (:295)
-    std::vector<uint8_t> raw(csize);
+    std::vector<uint8_t> raw((size_t)csize + 16, 0);         // fast_gunzip reads in 8-byte words
     if (fseek(f, (long)pos, SEEK_SET) != 0 || (csize && fread(raw.data(), 1, csize, f) != csize))
         return bail(WD_ERR_IO);
     fclose(f);
 
     SlotLease lease(ctx);
     wd_ctx::IngestSlot *sl = lease.slot;
-    int rc = slot_reserve(sl, (size_t)usize + 64);
+    int rc = slot_reserve(sl, (size_t)usize + 64 + kInflateSlack);
     if (rc)
         return rc;
-    z_stream zs;
-    memset(&zs, 0, sizeof(zs));
-    if (inflateInit2(&zs, 16 + MAX_WBITS) != Z_OK)
-        return WD_ERR_NOMEM;
-    zs.next_in = raw.data();
-    zs.avail_in = csize;
-    zs.next_out = sl->pinned;
-    zs.avail_out = usize;                                     // GzipFile.read(t_usize) (:301)
-    const int zr = inflate(&zs, Z_FINISH);
-    const size_t produced = (size_t)(zs.next_out - sl->pinned);
-    inflateEnd(&zs);
-    if (zr != Z_STREAM_END && zr != Z_OK && zr != Z_BUF_ERROR)
-        return WD_ERR_IO;
+    size_t produced = 0;
+    if (!ctx->fast_inflate || !fast_gunzip(raw.data(), csize, sl->pinned, (size_t)usize + 274, &produced) ||
+        produced > usize) {
+        z_stream zs;
+        memset(&zs, 0, sizeof(zs));
+        if (inflateInit2(&zs, 16 + MAX_WBITS) != Z_OK)
+            return WD_ERR_NOMEM;
+        zs.next_in = raw.data();
+        zs.avail_in = csize;
+        zs.next_out = sl->pinned;
+        zs.avail_out = usize;                                 // GzipFile.read(t_usize) (:301)
+        const int zr = inflate(&zs, Z_FINISH);
+        produced = (size_t)(zs.next_out - sl->pinned);
+        inflateEnd(&zs);
+        if (zr != Z_STREAM_END && zr != Z_OK && zr != Z_BUF_ERROR)
+            return WD_ERR_IO;
+    }
     const long long n_records = (long long)produced * 2;
     const int chunks = (int)((n_clusters + kCbclChunk - 1) / kCbclChunk);
     const size_t need = ((produced + 255) & ~(size_t)255) + (size_t)std::max(chunks, 1) * 4;
