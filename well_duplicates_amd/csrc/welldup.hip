@@ -983,7 +983,8 @@ int wd_scan_async(wd_ctx *ctx, int n_tiles, int L, int mode, int k, const uint8_
 
     // lane-per-target kernel: many small targets (every well a centre), Hamming family
     const bool dense_ok = !lev && ctx->early_exit && L >= 1 && ctx->k_max <= kDenseMaxK &&
-                          levels <= 8 && kk <= 2 && kk >= 0;      // levels: LDS budget (35 KB)
+                          levels <= 8 && kk <= 2 && kk >= 0 &&    // levels: 8-bit hit masks
+                          n_tiles <= 65535;                        // tiles ride in gridDim.y
     // (with k >= 2 nothing can die within the 2-cycle first round, so only on request)
     const bool use_dense = dense_ok && (ctx->dense_kernel == 1 ||
                                         (ctx->dense_kernel < 0 && ctx->T >= 65536 && kk <= 1));
