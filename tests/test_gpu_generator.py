@@ -87,3 +87,38 @@ def test_generated_targets_feed_the_scan(sc):
     got[got == INVALID_TARGET] = -1
     assert (got == np.where(valid[:, None] == 1, dups, -1)).all()
     tb.free()
+
+
+def test_full_size_all_centres_dense_path_equals_queue_kernel(sc):
+    """BASELINE configs[4] at full tile size (2743 x 1571 wells, every well a centre, 3 levels):
+    the dense path (signatures -> pairs -> verify, packed and unpacked) and the wave-per-target
+    queue kernel - which the golden fixtures pin - give the same per-target counts and tallies."""
+    from well_duplicates_amd.scanner import TileBatch
+    rows, cols, levels, L = workload.HISEQ4000_ROWS, workload.HISEQ4000_COLS, 3, 24
+    n = rows * cols
+    x, y = synth.honeycomb_pixels(rows, cols)
+    T, P = sc.targets_from_coords(x, y, None, levels=levels)
+    assert T == n and 35 * n < P < 36 * n + 1
+    spec = synth.SynthSpec(seed=21, n_clusters=n, row=cols, plant_per_64k=700, nocall_per_64k=300)
+    tb = TileBatch(sc, 2, L, n)
+    tb.fill_synthetic(spec, [(1, 1101), (1, 2228)], list(range(L)))
+    try:
+        sc.set_option("dense_kernel", 0)
+        want_b, want_pt = tb.count(0, 0, per_target=True)
+        for pack in (0, 1):
+            sc.set_option("dense_kernel", 1)
+            sc.set_option("dense_pack", pack)
+            got_b, got_pt = tb.count(0, 0, per_target=True)
+            assert (got_b == want_b).all(), pack
+            assert (got_pt == want_pt).all(), pack
+        assert want_b[:, 1 + levels:1 + 2 * levels].sum() > 10000          # duplicates were found
+        sc.set_option("dense_kernel", 0)
+        want_b1, _ = tb.count(1, 1)
+        sc.set_option("dense_kernel", -1)
+        sc.set_option("dense_pack", -1)
+        got_b1, _ = tb.count(1, 1)                                          # automatic choices
+        assert (got_b1 == want_b1).all()
+    finally:
+        sc.set_option("dense_kernel", -1)
+        sc.set_option("dense_pack", -1)
+        tb.free()
