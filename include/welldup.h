@@ -222,8 +222,8 @@ typedef struct wd_hit {
 int wd_hitlog_enable(wd_ctx *ctx, int64_t capacity);   /* 0 disables */
 int wd_hitlog_fetch(wd_ctx *ctx, wd_hit *out_host, int64_t max_records, int64_t *total_out);
 
-/* Timing of the dominant kernel with HIP events on the stream it runs on ("profile"=1):
- * total milliseconds and launches since the last reset. */
+/* Timing of the scan kernels with HIP events on the stream they run on ("profile" = n > 0: events
+ * around every n-th scan call): total milliseconds and timed launches since the last reset. */
 int wd_profile_get(wd_ctx *ctx, double *total_ms, int64_t *launches);
 int wd_profile_reset(wd_ctx *ctx);
 

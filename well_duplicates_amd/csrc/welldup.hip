@@ -139,7 +139,8 @@ struct wd_ctx {
     size_t rows_cap = 0;       // uint4 elements
     int dense_pack = -1;                       // option: -1 = by survivor count, 0 = never, 1 = always
     int fast_inflate = 1;                      // option: own gunzip first, zlib as referee (0 = zlib only)
-    int profile = 0;
+    int profile = 0;           // HIP events around every n-th scan (0 = off)
+    long long profile_seq = 0;
 
     // targets (device)
     int T = 0, levels = 0;
@@ -695,7 +696,8 @@ int wd_set_option(wd_ctx *ctx, const char *name, int64_t value)
     } else if (n == "batch_next") {
         ctx->batch_next = (int)value;
     } else if (n == "profile") {
-        ctx->profile = value ? 1 : 0;
+        ctx->profile = value < 0 ? 0 : (int)std::min<int64_t>(value, 1 << 20);   // n: every n-th scan
+        ctx->profile_seq = 0;
     } else if (n == "null_stream") {
         // run on the HIP null (legacy default) stream, e.g. to order with a framework that
         // uses it; 0 returns to the context's own stream
@@ -1002,7 +1004,8 @@ int wd_scan_async(wd_ctx *ctx, int n_tiles, int L, int mode, int k, const uint8_
     dim3 grid((unsigned)nblocks);
 
     std::pair<hipEvent_t, hipEvent_t> ev{nullptr, nullptr};
-    if (ctx->profile) {
+    const bool timed = ctx->profile > 0 && (ctx->profile_seq++ % ctx->profile) == 0;
+    if (timed) {
         if (!ctx->free_events.empty()) {
             ev = ctx->free_events.back();
             ctx->free_events.pop_back();
@@ -1053,7 +1056,7 @@ int wd_scan_async(wd_ctx *ctx, int n_tiles, int L, int mode, int k, const uint8_
         else launch_lev<8>(ctx, a, grid, strided);
     }
     WD_HIP(ctx, hipGetLastError());
-    if (ctx->profile) {
+    if (timed) {
         WD_HIP(ctx, hipEventRecord(ev.second, ctx->stream));
         ctx->events.push_back(ev);
     }
