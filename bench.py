@@ -18,8 +18,8 @@ performed compare = one unit of the reference report's `Wells` column
 Extra objects on the JSON line:
   roofline      HBM roofline of the dominant kernel (k_scan): algorithmic bytes
                 B = C*(L+4) + Tv*(L+5) + 8*(1+5*levels)*tiles per launch over the
-                kernel's mean duration over the K timed launches, measured with HIP events
-                on the launch stream.
+                kernel's mean duration, measured with HIP events on the launch stream around
+                every 8th launch of the timed region itself.
   cpu_baseline  the C oracle (oracle/welldup_oracle.c, -O3, OpenMP over tiles) on a bounded
                 sample of the same tiles, on this box's host cores.
 """
