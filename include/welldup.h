@@ -163,7 +163,8 @@ int wd_get_targets(wd_ctx *ctx, int32_t *centre, int32_t *lvl_off, int32_t *nbr)
  *                   the filter - enough to rebuild the reference's lane_dupl (:226, :265).
  *
  * wd_count_tiles: out_* are HOST pointers; synchronous; returns WD_ERR_EMPTY_LEVEL if a
- * valid target has an empty ring (:249).
+ * valid target has an empty ring (:249).  Its planes / filters may also point to HOST memory
+ * (each is then copied to the GPU first - convenient, and as slow as PCIe).
  * wd_scan_async: out_* are DEVICE pointers; work is queued on the context's stream and the
  * call returns at once; wd_scan_status() synchronises and returns the deferred status.
  */

@@ -535,6 +535,35 @@ def test_less_travelled_paths(sc):
         tb.free()
 
 
+def test_count_tiles_accepts_host_memory(sc):
+    """wd_count_tiles with planes / filters in host memory (numpy buffers), alone and mixed with
+    device-resident ones, gives what the device-resident batch gives."""
+    rng = np.random.default_rng(8)
+    spec = synth.SynthSpec(seed=61, n_clusters=6007, row=83, plant_per_64k=20000, nocall_per_64k=2000)
+    T, levels, L = 300, 4, 20
+    centre, lvl_off, nbr = _random_case(rng, spec.n_clusters, T, levels, ring=10)
+    sc.set_targets(centre, lvl_off, nbr)
+    tiles = [(1, 1101), (1, 1102), (2, 1101)]
+    tb = TileBatch(sc, len(tiles), L, spec.n_clusters)
+    tb.fill_synthetic(spec, tiles, list(range(L)))
+    try:
+        want_b, want_pt = tb.count(1, 1, per_target=True)
+        host_planes = [[np.ascontiguousarray(tb.download_plane(i, c)) for c in range(L)] for i in range(len(tiles))]
+        host_filt = [np.ascontiguousarray(tb.download_filter(i)) for i in range(len(tiles))]
+        ptrs = [[a.ctypes.data for a in row] for row in host_planes]
+        fptrs = [a.ctypes.data for a in host_filt]
+        got_b, got_pt = sc.count_tiles(ptrs, fptrs, spec.n_clusters, 1, 1, per_target=True)
+        assert (got_b == want_b).all() and (got_pt == want_pt).all()
+        # tile 1 stays on the device, odd cycles of tile 0 too
+        ptrs[1] = [tb.plane_ptr(1, c) for c in range(L)]
+        fptrs[1] = tb.filter_ptr(1)
+        ptrs[0] = [tb.plane_ptr(0, c) if c & 1 else ptrs[0][c] for c in range(L)]
+        got_b, got_pt = sc.count_tiles(ptrs, fptrs, spec.n_clusters, 1, 1, per_target=True)
+        assert (got_b == want_b).all() and (got_pt == want_pt).all()
+    finally:
+        tb.free()
+
+
 def test_fresh_context_requires_targets():
     s = Scanner(0)
     with pytest.raises(RuntimeError):

@@ -170,6 +170,8 @@ struct wd_ctx {
     size_t d_out_tile_cap = 0;
     uint32_t *d_out_pt = nullptr;
     size_t d_out_pt_cap = 0;
+    uint8_t *d_stage = nullptr;       // wd_count_tiles: device copies of planes handed over in host memory
+    size_t d_stage_cap = 0;
 
     // hit log
     wd_hit *d_hits = nullptr;
@@ -643,6 +645,7 @@ void wd_destroy(wd_ctx *ctx)
     (void)hipFree(ctx->d_gbase);
     (void)hipHostFree(ctx->h_status);
     (void)hipFree(ctx->d_out_tile);
+    (void)hipFree(ctx->d_stage);
     (void)hipFree(ctx->d_out_pt);
     (void)hipFree(ctx->d_hits);
     (void)hipFree(ctx->d_hit_count);
@@ -1099,6 +1102,51 @@ int wd_count_tiles(wd_ctx *ctx, int n_tiles, int L, int mode, int k, const uint8
         rc = grow(ctx, ctx->d_out_pt, ctx->d_out_pt_cap, n_pt);
         if (rc)
             return rc;
+    }
+    // Planes / filters may also be handed over in host memory (a numpy array's buffer, the bytes
+    // of a file just read): those are copied to a staging area first.  Convenient for a caller
+    // with no GPU runtime of its own; a caller that cares about time keeps its planes resident.
+    std::vector<const uint8_t *> dev_planes, dev_filter;
+    if (n_tiles > 0 && planes && filter && L >= 0 && N >= 0) {
+        auto on_device = [](const void *p) {
+            hipPointerAttribute_t at;
+            if (hipPointerGetAttributes(&at, p) != hipSuccess) {
+                (void)hipGetLastError();                     // plain malloc memory is simply unknown to HIP
+                return false;
+            }
+            return at.type == hipMemoryTypeDevice || at.type == hipMemoryTypeManaged;
+        };
+        const size_t n_planes = (size_t)n_tiles * (size_t)L;
+        const size_t n_pad = ((size_t)N + 255) & ~(size_t)255;
+        std::vector<char> host(n_planes + (size_t)n_tiles, 0);
+        size_t n_host = 0;
+        for (size_t i = 0; i < n_planes + (size_t)n_tiles; i++) {
+            const uint8_t *p = i < n_planes ? planes[i] : filter[i - n_planes];
+            if (!p)
+                return fail(ctx, WD_ERR_ARG, "null plane/filter pointer");
+            if (N > 0 && !on_device(p)) {
+                host[i] = 1;
+                n_host++;
+            }
+        }
+        if (n_host) {
+            rc = grow(ctx, ctx->d_stage, ctx->d_stage_cap, n_host * n_pad);
+            if (rc)
+                return rc;
+            dev_planes.assign(planes, planes + n_planes);
+            dev_filter.assign(filter, filter + n_tiles);
+            size_t slot = 0;
+            for (size_t i = 0; i < n_planes + (size_t)n_tiles; i++) {
+                if (!host[i])
+                    continue;
+                uint8_t *d = ctx->d_stage + slot++ * n_pad;
+                const uint8_t *src = i < n_planes ? planes[i] : filter[i - n_planes];
+                WD_HIP(ctx, hipMemcpyAsync(d, src, (size_t)N, hipMemcpyHostToDevice, ctx->stream));
+                (i < n_planes ? dev_planes[i] : dev_filter[i - n_planes]) = d;
+            }
+            planes = dev_planes.data();
+            filter = dev_filter.data();
+        }
     }
     rc = wd_scan_async(ctx, n_tiles, L, mode, k, planes, filter, N, (int64_t *)ctx->d_out_tile,
                        out_per_target ? ctx->d_out_pt : nullptr);
