@@ -1,12 +1,11 @@
 """Device neighbour-index generator (wd_targets_from_coords) against the numpy generator,
 which tests/test_synth_and_generator.py pins to the reference's prepare_cluster_indexes.py
 output (sha256) - sampled centres and the all-centres mode."""
-import os
 
 import numpy as np
 import pytest
 
-from helpers import GOLD, fixture_targets
+from helpers import fixture_targets
 from well_duplicates_amd import cluster_indexes, synth, workload
 from well_duplicates_amd.scanner import Scanner
 

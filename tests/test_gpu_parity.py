@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 
 from helpers import (FIXTURES, MODE_ID, blocks_to_reference, compact_tile, fixture_targets,
-                     lane_dupl_from, load_fixture, run_cycles)
+                     load_fixture, run_cycles)
 from oracle import oracle
 from well_duplicates_amd import cluster_indexes, synth
 from well_duplicates_amd.scanner import INVALID_TARGET, Scanner, TileBatch

@@ -3,7 +3,6 @@ reducer against the oracle's restatement of the reference's loops."""
 import io
 import os
 
-import numpy as np
 from hypothesis import given, settings, strategies as st
 
 from oracle import oracle

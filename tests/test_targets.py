@@ -2,7 +2,6 @@
 to the product parser (well_duplicates_amd.targets) and to the oracle's restatement."""
 import os
 
-import numpy as np
 import pytest
 
 from helpers import GOLD

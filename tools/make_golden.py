@@ -24,7 +24,6 @@ from __future__ import annotations
 
 import argparse
 import contextlib
-import gzip
 import hashlib
 import io
 import json
@@ -34,7 +33,6 @@ import subprocess
 import sys
 import tempfile
 
-import numpy as np
 
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 REF = "/root/reference"

@@ -16,7 +16,6 @@ from __future__ import annotations
 import os
 from typing import List, Sequence, Tuple
 
-import numpy as np
 
 
 def env_rank() -> Tuple[int, int, int]:
