@@ -111,12 +111,13 @@ def test_full_size_all_centres_dense_path_equals_queue_kernel(sc):
             assert (got_b == want_b).all(), pack
             assert (got_pt == want_pt).all(), pack
         assert want_b[:, 1 + levels:1 + 2 * levels].sum() > 10000          # duplicates were found
-        sc.set_option("dense_kernel", 0)
-        want_b1, _ = tb.count(1, 1)
-        sc.set_option("dense_kernel", -1)
-        sc.set_option("dense_pack", -1)
-        got_b1, _ = tb.count(1, 1)                                          # automatic choices
-        assert (got_b1 == want_b1).all()
+        for mode, k in ((1, 1), (2, 2)):                                    # automatic choices
+            sc.set_option("dense_kernel", 0)
+            want_b1, want_pt1 = tb.count(mode, k, per_target=True)
+            sc.set_option("dense_kernel", -1)
+            sc.set_option("dense_pack", -1)
+            got_b1, got_pt1 = tb.count(mode, k, per_target=True)
+            assert (got_b1 == want_b1).all() and (got_pt1 == want_pt1).all(), (mode, k)
     finally:
         sc.set_option("dense_kernel", -1)
         sc.set_option("dense_pack", -1)

@@ -395,7 +395,7 @@ def test_dense_all_centres_small(sc):
         assert blocks[:, 1 + levels:1 + 2 * levels].sum() > 0
     # a survivor queue far too small: what does not fit is finished inside the pairs kernel
     want = {}
-    for mode, k in ((0, 0), (1, 1)):
+    for mode, k in ((0, 0), (1, 1), (2, 2)):
         sc.set_option("dense_kernel", 1)
         want[(mode, k)] = tb.count(mode, k, per_target=True)
         sc.set_option("dense_queue_cap", 37)
@@ -419,7 +419,7 @@ def test_dense_short_reads(sc, L):
     tb.fill_synthetic(spec, [(1, 1101)], list(range(L)))
     planes, filt, c2, n2, _ = compact_tile(spec, 1, 1101, list(range(L)), centre, nbr)
     try:
-        for mode, k in ((0, 0), (1, 1), (1, 2)):
+        for mode, k in ((0, 0), (1, 1), (1, 2), (2, 2)):
             sc.set_option("dense_kernel", 1)
             bl, pt = tb.count(mode, k, per_target=True)
             valid, dups, lens, _ = oracle.count_tile(planes, filt, c2, lvl_off, n2, mode, k)
@@ -490,7 +490,7 @@ def test_less_travelled_paths(sc):
             sc.h2d(ptrs[i][c], tb.download_plane(i, c))
     host = [compact_tile(spec, lane, tile, list(range(L)), centre, nbr) for lane, tile in tiles]
     try:
-        for mode, k, dense, pack in ((0, 0, 1, 0), (0, 0, 1, 1), (1, 1, 1, 1), (1, 1, 1, 0), (2, 20, -1, -1),
+        for mode, k, dense, pack in ((0, 0, 1, 0), (0, 0, 1, 1), (1, 1, 1, 1), (1, 1, 1, 0), (2, 2, 1, -1), (2, 20, -1, -1),
                                      (2, 25, -1, -1)):
             sc.set_option("dense_kernel", dense)
             sc.set_option("dense_pack", pack)

@@ -69,3 +69,44 @@ def test_report_equals_reference_restatement(lane_dupl, verbose, levels):
     report.output_writer("3", 7, lane_dupl, levels=levels, verbose=verbose, out=buf2)
     if want is not None:
         assert buf2.getvalue() == want
+
+
+def _lev2_equal_length(a: str, b: str) -> int:
+    """The closed form the dense path uses for Levenshtein <= 2 on equal-length reads
+    (csrc/scan_dense.inc: lev2_window / lev2_words), restated on strings: the distance if it is
+    <= 2, else 3."""
+    mism = [i for i in range(len(a)) if a[i] != b[i]]
+    if len(mism) <= 2:
+        return len(mism)
+    p, t = mism[0], mism[-1]
+    if all(b[i] == a[i + 1] for i in range(p, t)):            # deletion at p, insertion at t
+        return 2
+    if all(b[i] == a[i - 1] for i in range(p + 1, t + 1)):    # insertion at p, deletion at t
+        return 2
+    return 3
+
+
+@settings(max_examples=3000, deadline=None)
+@given(st.data())
+def test_levenshtein_le2_closed_form(data):
+    alphabet = data.draw(st.sampled_from(["AC", "ACGTN", "A", "ACG"]))
+    n = data.draw(st.integers(1, 24))
+    a = data.draw(st.text(alphabet=alphabet, min_size=n, max_size=n))
+    kind = data.draw(st.integers(0, 2))
+    b = list(a)
+    if kind == 0:                                              # a few substitutions
+        for _ in range(data.draw(st.integers(0, 3))):
+            b[data.draw(st.integers(0, n - 1))] = data.draw(st.sampled_from(alphabet))
+    elif kind == 1 and n >= 2:                                 # delete one, insert one (+ maybe a substitution)
+        del b[data.draw(st.integers(0, n - 1))]
+        b.insert(data.draw(st.integers(0, n - 1)), data.draw(st.sampled_from(alphabet)))
+        if data.draw(st.booleans()):
+            b[data.draw(st.integers(0, n - 1))] = data.draw(st.sampled_from(alphabet))
+    else:
+        b = list(data.draw(st.text(alphabet=alphabet, min_size=n, max_size=n)))
+    b = "".join(b)
+    assert _lev2_equal_length(a, b) == min(oracle.py_levenshtein(a, b), 3)
+    # on a prefix the same test is a necessary condition (the signature filter relies on it)
+    if oracle.py_levenshtein(a, b) <= 2:
+        for cut in range(1, n):
+            assert _lev2_equal_length(a[:cut], b[:cut]) <= 2

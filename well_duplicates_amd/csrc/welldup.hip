@@ -408,9 +408,29 @@ int dense_reserve(wd_ctx *ctx, T *&ptr, size_t &cap, size_t need, const char *wh
     return WD_OK;
 }
 
+// Packed rows (64 bytes per well) are optional scratch for the Hamming family and mandatory for
+// Levenshtein <= 2; false if they cannot be had.
+bool dense_rows_reserve(wd_ctx *ctx, int n_tiles, int64_t N)
+{
+    const size_t rows_need = (size_t)n_tiles * (size_t)N * kRowGroups;
+    if (rows_need <= ctx->rows_cap)
+        return true;
+    if (hipStreamSynchronize(ctx->stream) != hipSuccess)
+        return false;
+    (void)hipFree(ctx->d_rows);
+    ctx->d_rows = nullptr;
+    ctx->rows_cap = 0;
+    if (hipMalloc((void **)&ctx->d_rows, std::max<size_t>(1, rows_need) * sizeof(uint4)) != hipSuccess) {
+        (void)hipGetLastError();
+        return false;
+    }
+    ctx->rows_cap = rows_need;
+    return true;
+}
+
 // The dense path of wd_scan_async (scan_dense.inc): signatures, pairs, verify, reduce.
 int launch_dense(wd_ctx *ctx, const ScanArgs &a, dim3 grid, int n_tiles, int64_t N, bool strided,
-                 size_t n_plane_ptrs, int tile_chunk)
+                 size_t n_plane_ptrs, int tile_chunk, bool lev2)
 {
     int rc = ensure_dense_tables(ctx);
     if (rc)
@@ -445,7 +465,7 @@ int launch_dense(wd_ctx *ctx, const ScanArgs &a, dim3 grid, int n_tiles, int64_t
     // diverse reads (9, 144, 950 for k = 0, 1, 2) plus one per duplicate pair; what does not fit
     // a block's region is finished inside k_dense_pairs, so this is a speed knob, not a limit
     const long long regions = (long long)n_tiles * ((a.T + kBlock - 1) / kBlock);
-    long long q_per = ctx->dense_queue_cap > 0 ? ctx->dense_queue_cap : (a.k <= 0 ? 128 : a.k == 1 ? 384 : 1536);
+    long long q_per = ctx->dense_queue_cap > 0 ? ctx->dense_queue_cap : (a.k <= 0 || lev2 ? 128 : a.k == 1 ? 384 : 1536);
     q_per = std::max<long long>(1, std::min<long long>(q_per, 7168));     // LDS: 8 bytes each
     d.q_per = (int)q_per;
     const size_t part_need = (size_t)n_tiles * kDenseSlots * d.partial_stride;
@@ -461,21 +481,15 @@ int launch_dense(wd_ctx *ctx, const ScanArgs &a, dim3 grid, int n_tiles, int64_t
     // packed rows are optional scratch (64 bytes per well): without them every survivor is
     // checked against the planes
     d.rows = nullptr;
-    d.pack_mode = ctx->dense_pack;
-    if (ctx->dense_pack != 0 && a.L > d.sig_cycles && a.L <= 40 * kRowGroups) {
-        const size_t rows_need = (size_t)n_tiles * (size_t)N * kRowGroups;
-        if (rows_need > ctx->rows_cap) {
-            WD_HIP(ctx, hipStreamSynchronize(ctx->stream));
-            (void)hipFree(ctx->d_rows);
-            ctx->d_rows = nullptr;
-            ctx->rows_cap = 0;
-            if (hipMalloc((void **)&ctx->d_rows, rows_need * sizeof(uint4)) == hipSuccess)
-                ctx->rows_cap = rows_need;
-            else
-                (void)hipGetLastError();
-        }
+    d.pack_mode = lev2 ? 1 : ctx->dense_pack;
+    d.lev2 = lev2 ? 1 : 0;
+    d.nbr = a.nbr;
+    if (d.pack_mode != 0 && a.L > d.sig_cycles && a.L <= 40 * kRowGroups && dense_rows_reserve(ctx, n_tiles, N))
         d.rows = ctx->d_rows;
-    }
+    if (lev2 && a.L <= d.sig_cycles && dense_rows_reserve(ctx, n_tiles, N))
+        d.rows = ctx->d_rows;                                // short reads: the verify kernel still compares rows
+    if (lev2 && !d.rows)
+        return fail(ctx, WD_ERR_NOMEM, "packed rows");
     // Checking one survivor against the planes touches ~2 (L - 10) cache lines (measured: 2.7 ns
     // per duplicate record at 150 bp, HBM line rate); packing streams every plane once and
     // writes 64 bytes per well (measured: 0.2 ms per 4.3 M-well tile).  Break-even is at about
@@ -506,14 +520,21 @@ int launch_dense(wd_ctx *ctx, const ScanArgs &a, dim3 grid, int n_tiles, int64_t
     else
         hipLaunchKernelGGL((k_dense_sig<false, false>), grid1, dim3(kBlock), 0, ctx->stream, d);
     const size_t q_lds = (size_t)d.q_per * sizeof(uint2);
-    if (a.k == 0 && ctx->nbr_t16)
-        hipLaunchKernelGGL((k_dense_pairs<true, true>), grid, dim3(kBlock), q_lds, ctx->stream, d);
-    else if (a.k == 0)
-        hipLaunchKernelGGL((k_dense_pairs<true, false>), grid, dim3(kBlock), q_lds, ctx->stream, d);
-    else if (ctx->nbr_t16)
-        hipLaunchKernelGGL((k_dense_pairs<false, true>), grid, dim3(kBlock), q_lds, ctx->stream, d);
+    const int pmode = lev2 ? 2 : (a.k == 0 ? 0 : 1);
+#define WD_LAUNCH_PAIRS(MODE)                                                                            \
+    do {                                                                                                 \
+        if (ctx->nbr_t16)                                                                                \
+            hipLaunchKernelGGL((k_dense_pairs<MODE, true>), grid, dim3(kBlock), q_lds, ctx->stream, d);  \
+        else                                                                                             \
+            hipLaunchKernelGGL((k_dense_pairs<MODE, false>), grid, dim3(kBlock), q_lds, ctx->stream, d); \
+    } while (0)
+    if (pmode == 0)
+        WD_LAUNCH_PAIRS(0);
+    else if (pmode == 1)
+        WD_LAUNCH_PAIRS(1);
     else
-        hipLaunchKernelGGL((k_dense_pairs<false, false>), grid, dim3(kBlock), q_lds, ctx->stream, d);
+        WD_LAUNCH_PAIRS(2);
+#undef WD_LAUNCH_PAIRS
     if (d.rows) {
         if (aligned4 && strided)
             hipLaunchKernelGGL((k_dense_pack<4, true>), grid4, dim3(kBlock), 0, ctx->stream, d);
@@ -987,12 +1008,16 @@ int wd_scan_async(wd_ctx *ctx, int n_tiles, int L, int mode, int k, const uint8_
         WD_HIP(ctx, hipMemsetAsync(ctx->d_hit_count, 0, sizeof(unsigned long long), ctx->stream));
 
     // lane-per-target kernel: many small targets (every well a centre), Hamming family
-    const bool dense_ok = !lev && ctx->early_exit && L >= 1 && ctx->k_max <= kDenseMaxK &&
+    // lev2: the reference's default, Levenshtein <= 2, has a closed form for equal-length reads
+    // (scan_dense.inc: lev2_window) and needs the packed rows, i.e. L <= 160
+    const bool lev2 = lev && kk == 2 && L <= 40 * kRowGroups;
+    const bool dense_ok = (!lev || lev2) && ctx->early_exit && L >= 1 && ctx->k_max <= kDenseMaxK &&
                           levels <= 8 && kk <= 2 && kk >= 0 &&    // levels: 8-bit hit masks
                           n_tiles <= 65535;                        // tiles ride in gridDim.y
-    // (with k >= 2 nothing can die within the 2-cycle first round, so only on request)
-    const bool use_dense = dense_ok && (ctx->dense_kernel == 1 ||
-                                        (ctx->dense_kernel < 0 && ctx->T >= 65536 && kk <= 1));
+    bool use_dense = dense_ok && (ctx->dense_kernel == 1 ||
+                                  (ctx->dense_kernel < 0 && ctx->T >= 65536 && (kk <= 1 || lev2)));
+    if (use_dense && lev2 && !dense_rows_reserve(ctx, n_tiles, N))
+        use_dense = false;                                   // no room for the rows: queue kernel
     const int chunks = (ctx->T + ctx->tpb - 1) / ctx->tpb;
     const int tile_chunk = std::max(1, std::min(ctx->dense_tile_chunk, n_tiles));
     // dense grid: 8 XCDs x (target blocks per XCD) x tile_chunk x (chunks of tiles), see k_dense_pairs
@@ -1021,7 +1046,7 @@ int wd_scan_async(wd_ctx *ctx, int n_tiles, int L, int mode, int k, const uint8_
     const bool use_queue = !lev && ctx->queue_kernel && ctx->early_exit && kk <= 254 &&
                            ctx->k_max <= (int64_t)kMaxPasses * kPass;
     if (use_dense) {
-        int rc = launch_dense(ctx, a, grid, n_tiles, N, strided, n_plane_ptrs, tile_chunk);
+        int rc = launch_dense(ctx, a, grid, n_tiles, N, strided, n_plane_ptrs, tile_chunk, lev2);
         if (rc)
             return rc;
     } else if (use_queue) {
