@@ -74,7 +74,7 @@ def dense_probe(device, n_tiles, rows, cols, levels=3, bases=150):
     """Kernel time of the dense path (scan_dense.inc) on n_tiles full-size tiles."""
     import numpy as np
     from well_duplicates_amd import synth
-    from well_duplicates_amd.scanner import Scanner, TileBatch, MODE_EQ
+    from well_duplicates_amd.scanner import Scanner, TileBatch, MODE_EQ, MODE_LEVENSHTEIN
     n = rows * cols
     x, y = synth.honeycomb_pixels(rows, cols)
     sc = Scanner(device)
@@ -89,6 +89,13 @@ def dense_probe(device, n_tiles, rows, cols, levels=3, bases=150):
         out = sc.malloc(n_tiles * ncnt * 8)
         sc.scan_async(tb.tables, n_tiles, bases, n, MODE_EQ, 0, out)      # builds the tables
         sc.set_option("profile", 1)
+        # the reference's default metric first (Levenshtein <= 2), then equality for the counters
+        sc.scan_async(tb.tables, n_tiles, bases, n, MODE_LEVENSHTEIN, 2, out)
+        sc.profile_reset()
+        for _ in range(3):
+            sc.scan_async(tb.tables, n_tiles, bases, n, MODE_LEVENSHTEIN, 2, out)
+        lev_ms, lev_n = sc.profile_get()
+        lev_ms /= max(1, lev_n)
         sc.profile_reset()
         for _ in range(3):
             sc.scan_async(tb.tables, n_tiles, bases, n, MODE_EQ, 0, out)
@@ -103,6 +110,8 @@ def dense_probe(device, n_tiles, rows, cols, levels=3, bases=150):
                "compares_per_s": round(compares / (ms * 1e-3), 1),
                "duplicates_found": int(blk[:, 1 + levels:1 + 2 * levels].sum()),
                "algorithmic_bytes": int(b_dense), "frac_of_hbm_peak": round(b_dense / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+               "levenshtein_k2_kernel_ms": round(lev_ms, 4),
+               "levenshtein_k2_compares_per_s": round(compares / (lev_ms * 1e-3), 1),
                "ring_generator_s": round(gen_s, 3)}
         tb.free()
         return res
