@@ -470,25 +470,24 @@ int launch_dense(wd_ctx *ctx, const ScanArgs &a, dim3 grid, int n_tiles, int64_t
     d.q_per = (int)q_per;
     const size_t part_need = (size_t)n_tiles * kDenseSlots * d.partial_stride;
     const size_t mask_need = (size_t)n_tiles * d.mask_stride;
-    if ((rc = dense_reserve(ctx, ctx->d_sig, ctx->sig_cap, (size_t)d.sig_stride * n_tiles, "signature planes")) ||
+    if ((rc = dense_reserve(ctx, ctx->d_sig, ctx->sig_cap, (size_t)d.sig_stride * n_tiles * (lev2 ? 2 : 1), "signature planes")) ||
         (rc = dense_reserve(ctx, ctx->d_partial, ctx->partial_cap, part_need, "counter slots")) ||
         (rc = dense_reserve(ctx, ctx->d_mask, ctx->mask_cap, mask_need, "hit masks")) ||
         (rc = dense_reserve(ctx, ctx->d_queue, ctx->queue_cap, (size_t)(regions * q_per), "survivor queue")) ||
         (rc = dense_reserve(ctx, ctx->d_qcnt, ctx->qcnt_cap, (size_t)regions, "survivor counts")))
         return rc;
     if (!ctx->d_cand)
-        WD_HIP(ctx, hipMalloc((void **)&ctx->d_cand, kDenseSlots * sizeof(uint32_t)));
+        WD_HIP(ctx, hipMalloc((void **)&ctx->d_cand, (kDenseSlots + 1) * sizeof(uint32_t)));
     // packed rows are optional scratch (64 bytes per well): without them every survivor is
     // checked against the planes
     d.rows = nullptr;
-    d.pack_mode = lev2 ? 1 : ctx->dense_pack;
+    d.pack_mode = ctx->dense_pack;
     d.lev2 = lev2 ? 1 : 0;
     d.nbr = a.nbr;
-    if (d.pack_mode != 0 && a.L > d.sig_cycles && a.L <= 40 * kRowGroups && dense_rows_reserve(ctx, n_tiles, N))
+    if ((d.pack_mode != 0 || lev2) && a.L > d.sig_cycles && a.L <= 40 * kRowGroups &&
+        dense_rows_reserve(ctx, n_tiles, N))
         d.rows = ctx->d_rows;
-    if (lev2 && a.L <= d.sig_cycles && dense_rows_reserve(ctx, n_tiles, N))
-        d.rows = ctx->d_rows;                                // short reads: the verify kernel still compares rows
-    if (lev2 && !d.rows)
+    if (lev2 && a.L > d.sig_cycles && !d.rows)               // (the caller reserved them)
         return fail(ctx, WD_ERR_NOMEM, "packed rows");
     // Checking one survivor against the planes touches ~2 (L - 10) cache lines (measured: 2.7 ns
     // per duplicate record at 150 bp, HBM line rate); packing streams every plane once and
@@ -496,8 +495,9 @@ int launch_dense(wd_ctx *ctx, const ScanArgs &a, dim3 grid, int n_tiles, int64_t
     // one record per 8192 plane bytes.
     d.pack_threshold = std::max<long long>(1, (long long)n_tiles * N * a.L / 8192);
     d.cand = ctx->d_cand;
-    WD_HIP(ctx, hipMemsetAsync(ctx->d_cand, 0, kDenseSlots * sizeof(uint32_t), ctx->stream));
+    WD_HIP(ctx, hipMemsetAsync(ctx->d_cand, 0, (kDenseSlots + 1) * sizeof(uint32_t), ctx->stream));
     d.sig = ctx->d_sig;
+    d.sig2 = (lev2 && a.L > kSigCycles) ? ctx->d_sig + (size_t)d.sig_stride * n_tiles : nullptr;
     d.partial = ctx->d_partial;
     d.mask = ctx->d_mask;
     d.queue = ctx->d_queue;
@@ -1016,7 +1016,7 @@ int wd_scan_async(wd_ctx *ctx, int n_tiles, int L, int mode, int k, const uint8_
                           n_tiles <= 65535;                        // tiles ride in gridDim.y
     bool use_dense = dense_ok && (ctx->dense_kernel == 1 ||
                                   (ctx->dense_kernel < 0 && ctx->T >= 65536 && (kk <= 1 || lev2)));
-    if (use_dense && lev2 && !dense_rows_reserve(ctx, n_tiles, N))
+    if (use_dense && lev2 && L > kSigCycles && !dense_rows_reserve(ctx, n_tiles, N))
         use_dense = false;                                   // no room for the rows: queue kernel
     const int chunks = (ctx->T + ctx->tpb - 1) / ctx->tpb;
     const int tile_chunk = std::max(1, std::min(ctx->dense_tile_chunk, n_tiles));
