@@ -59,6 +59,9 @@ def test_argument_defaults_and_flags():
     for missing in (["-s", "hiseq_x", "-r", "/r"], ["-f", "x", "-r", "/r"], ["-f", "x", "-s", "hiseq_x"]):
         with pytest.raises(SystemExit):
             cwd.parse_args(missing)
+    # this package's extra: every well a centre, rings from s.locs - then no targets file
+    a = cwd.parse_args(["--all-wells", "-s", "hiseq_x", "-r", "/r"])
+    assert a.all_wells and a.coord_file is None and a.slocs is None
 
 
 def test_mode_selection():

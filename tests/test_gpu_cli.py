@@ -95,3 +95,30 @@ def test_cli_two_ranks_one_gpu(tmp_path_factory, tmp_path):
     keep = ("center seq at", "well seq at", "edit distance:")
     log = [ln for ln in res.stderr.decode().splitlines() if ln.startswith(keep)]
     assert log == run["dup_log"]
+
+
+def test_cli_all_wells_equals_targets_file_with_every_well(tmp_path):
+    """--all-wells (rings generated on the GPU from the run's s.locs, dense scan path) prints the
+    report that a targets file listing every well gives through the ordinary path - for
+    equality, Hamming and the default Levenshtein <= 2."""
+    from well_duplicates_amd import cluster_indexes
+    rows, cols, levels, L = 36, 70, 3, 40
+    n = rows * cols
+    x, y = synth.honeycomb_pixels(rows, cols)
+    spec = synth.SynthSpec(seed=33, n_clusters=n, row=cols, plant_per_64k=4000, nocall_per_64k=500)
+    run_dir = str(tmp_path / "run")
+    synth.write_run_dir(spec, run_dir, [1], ["1101", "1102"], list(range(L)), slocs=synth.slocs_bytes(x, y))
+    tfile = str(tmp_path / "all.list")
+    with open(tfile, "w") as fh:
+        cluster_indexes.write_targets(cluster_indexes.generate(x, y, list(range(n)), levels), fh)
+    base = ["-s", "hiseq_x", "-r", run_dir, "-t", "1101,1102", "-i", "1", "-l", str(levels),
+            "--cycles", "0-%d" % L, "-q"]
+    for metric in (["-e", "0"], ["-e", "1", "--hamming"], ["-e", "2"]):
+        outs = []
+        for how in (["-f", tfile, "-n", str(n)], ["--all-wells"]):
+            out = io.StringIO()
+            with redirect_stdout(out):
+                assert cwd.main(base + metric + how) == 0
+            outs.append(out.getvalue())
+        assert outs[0] == outs[1], metric
+        assert "Targets: " in outs[0] and "/%d" % n in outs[0]

@@ -51,8 +51,8 @@ def parse_args(argv=None):
     selected reads from the coordinate file are compared with the centre read (edit distance,
     or Hamming distance with --hamming) on an AMD MI355X."""
     p = ArgumentParser(description=description, formatter_class=ArgumentDefaultsHelpFormatter)
-    p.add_argument("-f", "--coord_file", dest="coord_file", required=True,
-                   help="The file containing the random sample per tile.")
+    p.add_argument("-f", "--coord_file", dest="coord_file", required=False,
+                   help="The file containing the random sample per tile (required unless --all-wells).")
     p.add_argument("-e", "--edit_distance", dest="edit_distance", type=int, default=2,
                    help="max edit distance between two reads to count as duplicate")
     p.add_argument("-n", "--sample_size", dest="sample_size", type=int, default=2500,
@@ -92,9 +92,18 @@ def parse_args(argv=None):
                    help="reader threads (gunzip)")
     p.add_argument("-o", "--output", default=None,
                    help="write the report to this file instead of stdout")
+    p.add_argument("--all-wells", action="store_true",
+                   help="every well of a tile is a centre (no sampling, no targets file): the rings of "
+                        "-l levels are generated on the GPU from the run's s.locs with the rules of "
+                        "prepare_cluster_indexes.py; the per-duplicate log is not written in this mode")
+    p.add_argument("--slocs", default=None,
+                   help="s.locs file for --all-wells (default: <run>/Data/Intensities/s.locs)")
     p.add_argument("--strict", action="store_true",
                    help="reproduce the reference's ZeroDivisionError on a lane without duplicates")
-    return p.parse_args(argv)
+    args = p.parse_args(argv)
+    if not args.coord_file and not args.all_wells:
+        p.error("the following arguments are required: -f/--coord_file (or --all-wells)")
+    return args
 
 
 def _decode(seq_bytes: np.ndarray) -> str:
@@ -190,9 +199,15 @@ def main(argv=None):
     cycle_list = [c for s, e in cycles for c in range(s, e)]
     mode, k = compare_mode(args.edit_distance, args.hamming)
 
-    targets = load_targets(filename=args.coord_file, levels=args.level + 1, limit=args.sample_size)
-    csr = targets.to_csr(args.level)
-    wells = np.unique(np.asarray(targets.get_all_indices(), dtype=np.int64))
+    if args.all_wells:
+        from . import cluster_indexes
+        xy = cluster_indexes.read_slocs(args.slocs or os.path.join(args.run, "Data", "Intensities", "s.locs"))
+        targets = csr = None
+        wells = np.zeros(0, dtype=np.int64)
+    else:
+        targets = load_targets(filename=args.coord_file, levels=args.level + 1, limit=args.sample_size)
+        csr = targets.to_csr(args.level)
+        wells = np.unique(np.asarray(targets.get_all_indices(), dtype=np.int64))
     reader = bcl_direct_reader.BCLReader(args.run)
 
     from . import dist as wdist
@@ -210,12 +225,19 @@ def main(argv=None):
     out_fh = open(args.output, "w") if (args.output and rank == 0) else None
     try:
         with Scanner(device) as sc:
-            sc.set_targets(*csr)
+            if args.all_wells:
+                n_targets, n_slots = sc.targets_from_coords(xy[0], xy[1], None, levels=levels)
+                log("All %i wells are centres: %i neighbour slots in %i levels" % (n_targets, n_slots, levels))
+                # the scan needs nothing of the rings on the host; the log of single duplicates is off
+                csr = (np.zeros(0, np.int32), np.zeros((0, levels + 1), np.int32), np.zeros(0, np.int32))
+            else:
+                n_targets = len(targets)
+                sc.set_targets(*csr)
             for lane in lanes:
                 mine = wdist.shard(tiles, rank, world)
                 counts, logs = scan_lane(sc, reader, lane, mine, cycle_list, mode, k, csr, wells,
                                          max(1, args.tile_batch), args.threads,
-                                         0 if args.quiet else len(cycles))
+                                         0 if (args.quiet or args.all_wells) else len(cycles))
                 if world > 1:
                     import torch
                     import torch.distributed as tdist
@@ -233,7 +255,7 @@ def main(argv=None):
                     for t in tiles:
                         for line in logs.get(t, ()):
                             log(line)
-                    report.write_report(lane, len(targets), counts, verbose=not args.summary_only,
+                    report.write_report(lane, n_targets, counts, verbose=not args.summary_only,
                                         strict=args.strict, out=out_fh)
     finally:
         if out_fh:
