@@ -22,6 +22,9 @@ def main():
     ap.add_argument("--dir", default="/tmp/wd_e2e")
     ap.add_argument("--threads", type=int, default=16)
     ap.add_argument("--extra", default="")
+    ap.add_argument("--levels", type=int, default=5)
+    ap.add_argument("--metric", default="-e 0 --hamming", help='e.g. "-e 2" for the reference default')
+    ap.add_argument("--all-wells", action="store_true", help="every well a centre (rings from s.locs)")
     ap.add_argument("--qual-levels", type=int, default=7, help="binned qualities -> compressible planes")
     ap.add_argument("--gzip-level", type=int, default=6)
     a = ap.parse_args()
@@ -34,16 +37,19 @@ def main():
         t0 = time.time()
         os.makedirs(a.dir, exist_ok=True)
         x, y = synth.honeycomb_pixels(rows, cols)
-        synth.write_run_dir(spec, a.dir, [1], tiles, list(range(a.cycles)), compresslevel=a.gzip_level)
+        synth.write_run_dir(spec, a.dir, [1], tiles, list(range(a.cycles)), compresslevel=a.gzip_level,
+                            slocs=synth.slocs_bytes(x, y))
         centres = cluster_indexes.sample_centres(rows * cols, 2500, 13)
         with open(tfile, "w") as fh:
             cluster_indexes.write_targets(cluster_indexes.generate(x, y, centres, 5), fh)
         open(marker, "w").write("ok")
         print("wrote run dir in %.1f s" % (time.time() - t0), file=sys.stderr)
     gz = sum(os.path.getsize(os.path.join(dp, f)) for dp, _, fs in os.walk(a.dir) for f in fs if f.endswith(".gz"))
-    argv = ["-f", tfile, "-n", "2500", "-l", "5", "-s", "hiseq_x", "-r", a.dir, "-i", "1",
-            "-t", ",".join(tiles), "--cycles", "0-%d" % a.cycles, "-e", "0", "--hamming", "-q", "-S",
-            "--threads", str(a.threads)] + a.extra.split()
+    argv = ["-f", tfile, "-n", "2500", "-l", str(a.levels), "-s", "hiseq_x", "-r", a.dir, "-i", "1",
+            "-t", ",".join(tiles), "--cycles", "0-%d" % a.cycles, "-q", "-S",
+            "--threads", str(a.threads)] + a.metric.split() + a.extra.split()
+    if a.all_wells:
+        argv.append("--all-wells")
     for rep in range(2):
         t0 = time.time()
         buf = io.StringIO()
