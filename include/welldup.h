@@ -81,7 +81,7 @@ int wd_synchronize(wd_ctx *ctx);
  * "queue_first" (0 = from k), "batch_first" (4), "batch_next" (4), "profile" (0),
  * "null_stream" (0), "dense_kernel" (-1 = automatic: lane-per-target kernel when T >= 65536),
  * "dense_tile_chunk" (4: tiles that walk a block of targets together in the dense path),
- * "dense_queue_cap" (0 = from k: survivor entries per 256 targets), "dense_pack" (-1 = pack all
+ * "dense_queue_cap" (0 = 128: survivor entries per 256 targets), "dense_pack" (-1 = pack all
  * cycles into rows when the batch has many survivors, 0 = never, 1 = always), "fast_inflate" (1:
  * the loaders try the library's own gunzip before zlib; the environment variable WD_FAST_INFLATE
  * sets the default).

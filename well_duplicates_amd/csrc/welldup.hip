@@ -461,11 +461,12 @@ int launch_dense(wd_ctx *ctx, const ScanArgs &a, dim3 grid, int n_tiles, int64_t
     d.sig_stride = (N + 127) & ~(long long)127;
     d.partial_stride = ((1 + 5 * a.levels) + 15) & ~15;              // whole 128-byte lines per slot
     d.mask_stride = (((long long)a.T + 3) / 4 + 31) & ~31ll;
-    // survivors per block of 256 targets: 36 * P(<= k mismatches in 5 cycles) per target on
-    // diverse reads (9, 144, 950 for k = 0, 1, 2) plus one per duplicate pair; what does not fit
-    // a block's region is finished inside k_dense_pairs, so this is a speed knob, not a limit
+    // survivors per block of 256 targets: on diverse reads almost nobody passes 10 cycles (36 x
+    // P(<= 2 mismatches in 10) = 0.015 per target; ~8 per block for Levenshtein <= 2), so the
+    // region holds mostly duplicate pairs; what does not fit is finished inside k_dense_pairs (or,
+    // for Levenshtein, by k_dense_verify): a speed knob, not a limit
     const long long regions = (long long)n_tiles * ((a.T + kBlock - 1) / kBlock);
-    long long q_per = ctx->dense_queue_cap > 0 ? ctx->dense_queue_cap : (a.k <= 0 || lev2 ? 128 : a.k == 1 ? 384 : 1536);
+    long long q_per = ctx->dense_queue_cap > 0 ? ctx->dense_queue_cap : 128;
     q_per = std::max<long long>(1, std::min<long long>(q_per, 7168));     // LDS: 8 bytes each
     d.q_per = (int)q_per;
     const size_t part_need = (size_t)n_tiles * kDenseSlots * d.partial_stride;
@@ -1014,8 +1015,7 @@ int wd_scan_async(wd_ctx *ctx, int n_tiles, int L, int mode, int k, const uint8_
     const bool dense_ok = (!lev || lev2) && ctx->early_exit && L >= 1 && ctx->k_max <= kDenseMaxK &&
                           levels <= 8 && kk <= 2 && kk >= 0 &&    // levels: 8-bit hit masks
                           n_tiles <= 65535;                        // tiles ride in gridDim.y
-    bool use_dense = dense_ok && (ctx->dense_kernel == 1 ||
-                                  (ctx->dense_kernel < 0 && ctx->T >= 65536 && (kk <= 1 || lev2)));
+    bool use_dense = dense_ok && (ctx->dense_kernel == 1 || (ctx->dense_kernel < 0 && ctx->T >= 65536));
     if (use_dense && lev2 && L > kSigCycles && !dense_rows_reserve(ctx, n_tiles, N))
         use_dense = false;                                   // no room for the rows: queue kernel
     const int chunks = (ctx->T + ctx->tpb - 1) / ctx->tpb;
