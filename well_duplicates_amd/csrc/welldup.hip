@@ -152,6 +152,8 @@ struct wd_ctx {
     void *d_nbr_t = nullptr;          // built on first use of the dense path: int16 offsets or int32 indices
     bool nbr_t16 = false;
     int32_t *d_rel_t = nullptr;       // dense path: ring ends per target, level-major
+    void *d_udelta = nullptr;         // dense path: shared neighbour offsets of uniform groups (type of d_nbr_t)
+    uint8_t *d_guni = nullptr;        // dense path: which groups are uniform
     long long *d_gbase = nullptr;
     bool has_targets = false;
     bool has_empty_level = false;
@@ -334,6 +336,10 @@ void set_group_bases(wd_ctx *ctx, const int32_t *lvl_off, int T, int levels)
     (void)hipFree(ctx->d_nbr_t);
     (void)hipFree(ctx->d_gbase);
     (void)hipFree(ctx->d_rel_t);
+    (void)hipFree(ctx->d_udelta);
+    (void)hipFree(ctx->d_guni);
+    ctx->d_udelta = nullptr;
+    ctx->d_guni = nullptr;
     ctx->d_nbr_t = nullptr;
     ctx->d_gbase = nullptr;
     ctx->d_rel_t = nullptr;
@@ -353,6 +359,8 @@ int ensure_dense_tables(wd_ctx *ctx)
     if (ctx->T > 0)
         hipLaunchKernelGGL(k_transpose_off, dim3((ctx->T + kBlock - 1) / kBlock), dim3(kBlock), 0, ctx->stream,
                            ctx->d_lvl_off, ctx->d_rel_t, ctx->T, ctx->levels);
+    WD_HIP(ctx, hipMalloc(&ctx->d_udelta, std::max<size_t>(1, (size_t)(total / kWave)) * sizeof(int32_t)));
+    WD_HIP(ctx, hipMalloc((void **)&ctx->d_guni, std::max<size_t>(1, (size_t)groups)));
     // int16 offsets from the centre if they all fit (half the index stream), else int32 indices
     const size_t n_el = (size_t)std::max<long long>(1, total);
     WD_HIP(ctx, hipMalloc(&ctx->d_nbr_t, n_el * sizeof(int16_t)));
@@ -361,7 +369,7 @@ int ensure_dense_tables(wd_ctx *ctx)
         WD_HIP(ctx, hipMemsetAsync(ctx->d_status, 0, sizeof(uint32_t), ctx->stream));
         hipLaunchKernelGGL((k_transpose_nbr<int16_t>), dim3(groups), dim3(kWave), 0, ctx->stream, ctx->d_centre,
                            ctx->d_lvl_off, ctx->d_nbr, ctx->d_gbase, (int16_t *)ctx->d_nbr_t, ctx->T, ctx->levels,
-                           ctx->d_status);
+                           ctx->d_status, (int16_t *)ctx->d_udelta, ctx->d_guni);
         uint32_t wide = 0;
         WD_HIP(ctx, hipMemcpyAsync(&wide, ctx->d_status, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
         WD_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -373,7 +381,7 @@ int ensure_dense_tables(wd_ctx *ctx)
             WD_HIP(ctx, hipMalloc(&ctx->d_nbr_t, n_el * sizeof(int32_t)));
             hipLaunchKernelGGL((k_transpose_nbr<int32_t>), dim3(groups), dim3(kWave), 0, ctx->stream, ctx->d_centre,
                                ctx->d_lvl_off, ctx->d_nbr, ctx->d_gbase, (int32_t *)ctx->d_nbr_t, ctx->T,
-                               ctx->levels, ctx->d_status);
+                               ctx->levels, ctx->d_status, (int32_t *)ctx->d_udelta, ctx->d_guni);
         }
     }
     WD_HIP(ctx, hipGetLastError());
@@ -444,6 +452,8 @@ int launch_dense(wd_ctx *ctx, const ScanArgs &a, dim3 grid, int n_tiles, int64_t
     d.nbr_t = ctx->d_nbr_t;
     d.idx16 = ctx->nbr_t16 ? 1 : 0;
     d.rel_t = ctx->d_rel_t;
+    d.udelta = ctx->d_udelta;
+    d.guni = ctx->d_guni;
     d.gbase = ctx->d_gbase;
     d.out_per_target = a.out_per_target;
     d.rare = a.rare;
@@ -657,6 +667,8 @@ void wd_destroy(wd_ctx *ctx)
     (void)hipFree(ctx->d_rare);
     (void)hipFree(ctx->d_nbr_t);
     (void)hipFree(ctx->d_rel_t);
+    (void)hipFree(ctx->d_udelta);
+    (void)hipFree(ctx->d_guni);
     (void)hipFree(ctx->d_sig);
     (void)hipFree(ctx->d_partial);
     (void)hipFree(ctx->d_mask);
