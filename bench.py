@@ -58,6 +58,8 @@ def parse():
     ap.add_argument("--cpu-tiles", type=int, default=8, help="tiles in the CPU-baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-steps", type=int, default=20)
+    ap.add_argument("--interleaved-tiles", type=int, default=96,
+                    help="tiles of the interleaved-layout measurement under other_modes; 0 = skip")
     ap.add_argument("--dense-tiles", type=int, default=4,
                     help="tiles of the all-centres probe (BASELINE configs[4] shape: every well a centre, "
                          "3 levels, 150 bp) reported under other_modes; 0 = skip")
@@ -309,6 +311,31 @@ def main():
                            "compares_per_s": round(compares_rank / (o_ms / max(1, o_n) * 1e-3), 1)}
         sc.scan_async(tb.tables, args.tiles, L, n_clusters, mode, k, my_rows.data_ptr())   # restore counters
         sc.scan_status()
+        # the resident-layout option: the same tiles with their cycles interleaved by four
+        # (what the loaders could write at no extra cost; include/welldup.h, wd_interleave4)
+        if rank == 0 and world == 1 and args.interleaved_tiles > 0:
+            n_il = min(args.interleaved_tiles, args.tiles)
+            il = TileBatch(sc, n_il, L, n_clusters, interleave=4)
+            il.fill_synthetic(spec, lane_tile[:n_il], list(range(L)))
+            scratch = torch.zeros((n_il, ncnt), dtype=torch.int64, device="cuda")
+            sc.set_option("well_stride", 4)
+            sc.scan_async(il.tables, n_il, L, n_clusters, mode, k, scratch.data_ptr())
+            sc.profile_reset()
+            for _ in range(10):
+                sc.scan_async(il.tables, n_il, L, n_clusters, mode, k, scratch.data_ptr())
+            i_ms, i_n = sc.profile_get()
+            sc.set_option("well_stride", 1)
+            sc.scan_status()
+            torch.cuda.synchronize()
+            same = bool((scratch.cpu().numpy() == mine[:n_il]).all())
+            i_ms /= max(1, i_n)
+            c_il = int(mine[:n_il, 1:1 + levels].sum())
+            b_il = c_il * (L + 4) + int(mine[:n_il, 0].sum()) * (L + 5) + 8 * ncnt * n_il
+            other["interleaved_by_4"] = {
+                "tiles": n_il, "kernel_ms": round(i_ms, 5), "compares_per_s": round(c_il / (i_ms * 1e-3), 1),
+                "frac_of_hbm_peak": round(b_il / (i_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                "same_counters_as_plane_layout": same}
+            il.free()
     sc.set_option("profile", 0)
     # BASELINE configs[4] in small: every well of a tile is a centre (device-generated rings,
     # 3 levels), 150 bp, 2 % planted duplicates as in SURVEY.md 8d; its own context and planes

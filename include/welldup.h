@@ -84,7 +84,7 @@ int wd_synchronize(wd_ctx *ctx);
  * "dense_queue_cap" (0 = 128: survivor entries per 256 targets), "dense_pack" (-1 = pack all
  * cycles into rows when the batch has many survivors, 0 = never, 1 = always), "fast_inflate" (1:
  * the loaders try the library's own gunzip before zlib; the environment variable WD_FAST_INFLATE
- * sets the default).
+ * sets the default), "well_stride" (1 = a plane per cycle; 4 = interleaved, see wd_interleave4).
  * Unknown names return WD_ERR_ARG. */
 int wd_set_option(wd_ctx *ctx, const char *name, int64_t value);
 int wd_get_option(wd_ctx *ctx, const char *name, int64_t *value);
@@ -190,6 +190,17 @@ int wd_scan_status(wd_ctx *ctx);
  */
 int wd_load_bcl_gz(wd_ctx *ctx, const char *path, uint8_t *dst_dev, int64_t n_clusters);
 int wd_load_filter(wd_ctx *ctx, const char *path, uint8_t *dst_dev, int64_t n_clusters);
+/* Resident layout option for the equality / Hamming scan of sampled targets.  A line of HBM holds
+ * 128 wells of ONE cycle in the BCL files' plane-per-cycle layout, and the scan wants ~11
+ * neighbouring wells of SEVERAL cycles: with the cycles interleaved by four ([group of 4 cycles]
+ * [well][4 bytes]) one dword is a well's first round and the scan touches half the lines.
+ * wd_interleave4 builds one group from up to four device planes (NULL = cycle beyond the read),
+ * queued on the context's stream; dst_dev: 4 * n_clusters bytes, 4-byte aligned.  A scan of such
+ * a batch passes plane pointers that describe it (cycle c of a tile at base + (c / 4) * group
+ * stride + c % 4) after wd_set_option(ctx, "well_stride", 4); other kernels (Levenshtein, the
+ * dense path) answer WD_ERR_UNSUPPORTED. */
+int wd_interleave4(wd_ctx *ctx, const uint8_t *const src[4], int64_t n_clusters, uint8_t *dst_dev);
+
 /* The host-side gunzip behind the two loaders, exposed for testing and reuse; no GPU involved.
  * All members of a gzip file src[0, src_len) -> dst (at most dst_cap bytes), *produced = bytes
  * written.  mode 0: zlib.  mode 1: the library's own RFC 1951/1952 decoder (CRC-32 and length of

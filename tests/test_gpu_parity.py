@@ -535,6 +535,46 @@ def test_less_travelled_paths(sc):
         tb.free()
 
 
+@pytest.mark.parametrize("L", [1, 3, 4, 5, 8, 23, 50])
+def test_interleaved_layout_equals_plane_layout(sc, L):
+    """The resident layout option (cycles interleaved by four, include/welldup.h wd_interleave4):
+    the same tiles stored both ways give the same per-target counts, tallies and hit log;
+    kernels that only read planes refuse the layout."""
+    rng = np.random.default_rng(400 + L)
+    spec = synth.SynthSpec(seed=70 + L, n_clusters=9001, row=97, plant_per_64k=22000, nocall_per_64k=2500)
+    T, levels = 500, 4
+    centre, lvl_off, nbr = _random_case(rng, spec.n_clusters, T, levels, ring=40)
+    sc.set_targets(centre, lvl_off, nbr)
+    tiles = [(1, 1101), (3, 2210)]
+    plane = TileBatch(sc, len(tiles), L, spec.n_clusters)
+    inter = TileBatch(sc, len(tiles), L, spec.n_clusters, interleave=4)
+    try:
+        plane.fill_synthetic(spec, tiles, list(range(L)))
+        inter.fill_synthetic(spec, tiles, list(range(L)))
+        for c in range(L):
+            assert (inter.download_plane(1, c) == plane.download_plane(1, c)).all()
+        for mode, k in ((0, 0), (1, 1), (1, 2), (1, 3), (1, L), (2, 1)):
+            sc.hitlog_enable(100000)
+            want = plane.count(mode, k, per_target=True)
+            want_hits, want_total = sc.hitlog_fetch(100000)
+            got = inter.count(mode, k, per_target=True)
+            hits, total = sc.hitlog_fetch(100000)
+            sc.hitlog_enable(0)
+            assert (got[0] == want[0]).all() and (got[1] == want[1]).all(), (L, mode, k)
+            key = lambda h: (int(h["tile"]), int(h["target"]), int(h["slot"]), int(h["dist"]))
+            assert total == want_total and sorted(map(key, hits)) == sorted(map(key, want_hits))
+        if L >= 3:
+            with pytest.raises(RuntimeError):                 # Levenshtein <= 2 reads planes only
+                inter.count(2, 2)
+        sc.set_option("dense_kernel", 1)
+        with pytest.raises(RuntimeError):
+            inter.count(0, 0)
+    finally:
+        sc.set_option("dense_kernel", -1)
+        plane.free()
+        inter.free()
+
+
 def test_count_tiles_accepts_host_memory(sc):
     """wd_count_tiles with planes / filters in host memory (numpy buffers), alone and mixed with
     device-resident ones, gives what the device-resident batch gives."""

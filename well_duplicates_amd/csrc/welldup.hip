@@ -139,6 +139,7 @@ struct wd_ctx {
     size_t rows_cap = 0;       // uint4 elements
     int dense_pack = -1;                       // option: -1 = by survivor count, 0 = never, 1 = always
     int fast_inflate = 1;                      // option: own gunzip first, zlib as referee (0 = zlib only)
+    int well_stride = 1;                       // option: 1 = a plane per cycle, 4 = cycles interleaved by four
     int profile = 0;           // HIP events around every n-th scan (0 = off)
     long long profile_seq = 0;
 
@@ -302,6 +303,10 @@ template <bool STRIDED>
 int launch_queue(wd_ctx *ctx, const ScanArgs &a, dim3 grid)
 {
     const size_t lds = (size_t)scan_q_lds_dwords(a.levels, a.tpb) * sizeof(uint32_t);
+    if (STRIDED && ctx->well_stride == 4) {                 // interleaved: one dword = the first round
+        hipLaunchKernelGGL((k_scan_q<true, 4, 0, STRIDED ? 4 : 1>), grid, dim3(kBlock), lds, ctx->stream, a);
+        return 0;
+    }
     // A random neighbour survives r cycles with <= k mismatches with probability
     // sum_{i<=k} C(r,i) 0.75^i 0.25^(r-i); the first round should leave a few percent alive.
     int first = ctx->queue_first;
@@ -748,6 +753,10 @@ int wd_set_option(wd_ctx *ctx, const char *name, int64_t value)
         if (value < 1 || value > 1024)
             return WD_ERR_ARG;
         ctx->dense_tile_chunk = (int)value;
+    } else if (n == "well_stride") {
+        if (value != 1 && value != 4)
+            return WD_ERR_ARG;
+        ctx->well_stride = (int)value;
     } else if (n == "fast_inflate") {
         ctx->fast_inflate = value ? 1 : 0;
     } else if (n == "dense_pack") {
@@ -784,6 +793,7 @@ int wd_get_option(wd_ctx *ctx, const char *name, int64_t *value)
     else if (n == "dense_queue_cap") *value = ctx->dense_queue_cap;
     else if (n == "dense_pack") *value = ctx->dense_pack;
     else if (n == "fast_inflate") *value = ctx->fast_inflate;
+    else if (n == "well_stride") *value = ctx->well_stride;
     else if (n == "null_stream") *value = ctx->stream == nullptr ? 1 : 0;
     else if (n == "queue_first") *value = ctx->queue_first;
     else return fail(ctx, WD_ERR_ARG, "unknown option " + n);
@@ -962,14 +972,32 @@ int wd_scan_async(wd_ctx *ctx, int n_tiles, int L, int mode, int k, const uint8_
     // pointer tables: uniform plane stride -> per-tile base only
     bool strided = L > 0;
     int64_t stride = 0;
-    if (L > 1)
-        stride = (int64_t)(planes[1] - planes[0]);
-    for (int i = 0; i < n_tiles && strided; i++)
-        for (int c = 1; c < L; c++)
-            if ((int64_t)(planes[(size_t)i * L + c] - planes[(size_t)i * L]) != stride * c) {
-                strided = false;
-                break;
-            }
+    const int ws = ctx->well_stride;
+    if (ws == 4) {
+        // cycles interleaved by four: cycle c of a tile lives at base + (c / 4) * group stride +
+        // c % 4, wells 4 bytes apart; the pointers must say exactly that
+        if (L > 4)
+            stride = (int64_t)(planes[4] - planes[0]);
+        for (int i = 0; i < n_tiles; i++) {
+            const uint8_t *b = planes[(size_t)i * L];
+            if (L > 0 && ((uintptr_t)b & 3u))
+                return fail(ctx, WD_ERR_ARG, "interleaved planes must start 4-byte aligned");
+            for (int c = 0; c < L; c++)
+                if (planes[(size_t)i * L + c] != b + (int64_t)(c >> 2) * stride + (c & 3))
+                    return fail(ctx, WD_ERR_ARG, "plane pointers do not describe the interleaved layout");
+        }
+        if (N > (1ll << 30))
+            return fail(ctx, WD_ERR_UNSUPPORTED, "interleaved layout: more than 2^30 wells");
+    } else {
+        if (L > 1)
+            stride = (int64_t)(planes[1] - planes[0]);
+        for (int i = 0; i < n_tiles && strided; i++)
+            for (int c = 1; c < L; c++)
+                if ((int64_t)(planes[(size_t)i * L + c] - planes[(size_t)i * L]) != stride * c) {
+                    strided = false;
+                    break;
+                }
+    }
     const size_t n_plane_ptrs = strided ? (size_t)n_tiles : (size_t)n_tiles * L;
     std::vector<const uint8_t *> tbl(n_plane_ptrs + n_tiles);
     for (int i = 0; i < n_tiles; i++) {
@@ -1030,6 +1058,8 @@ int wd_scan_async(wd_ctx *ctx, int n_tiles, int L, int mode, int k, const uint8_
     bool use_dense = dense_ok && (ctx->dense_kernel == 1 || (ctx->dense_kernel < 0 && ctx->T >= 65536));
     if (use_dense && lev2 && L > kSigCycles && !dense_rows_reserve(ctx, n_tiles, N))
         use_dense = false;                                   // no room for the rows: queue kernel
+    if (ws == 4 && ctx->dense_kernel < 0)
+        use_dense = false;                                   // the dense path reads planes
     const int chunks = (ctx->T + ctx->tpb - 1) / ctx->tpb;
     const int tile_chunk = std::max(1, std::min(ctx->dense_tile_chunk, n_tiles));
     // dense grid: 8 XCDs x (target blocks per XCD) x tile_chunk x (chunks of tiles), see k_dense_pairs
@@ -1043,6 +1073,12 @@ int wd_scan_async(wd_ctx *ctx, int n_tiles, int L, int mode, int k, const uint8_
         return fail(ctx, WD_ERR_UNSUPPORTED, "grid too large; raise targets_per_block");
     dim3 grid((unsigned)nblocks);
 
+    const bool use_queue = !lev && ctx->queue_kernel && ctx->early_exit && kk <= 254 &&
+                           ctx->k_max <= (int64_t)kMaxPasses * kPass;
+    if (ws == 4 && (use_dense || !use_queue || !strided))
+        return fail(ctx, WD_ERR_UNSUPPORTED,
+                    "the interleaved layout is read by the equality / Hamming queue kernel only");
+
     std::pair<hipEvent_t, hipEvent_t> ev{nullptr, nullptr};
     const bool timed = ctx->profile > 0 && (ctx->profile_seq++ % ctx->profile) == 0;
     if (timed) {
@@ -1055,8 +1091,6 @@ int wd_scan_async(wd_ctx *ctx, int n_tiles, int L, int mode, int k, const uint8_
         }
         WD_HIP(ctx, hipEventRecord(ev.first, ctx->stream));
     }
-    const bool use_queue = !lev && ctx->queue_kernel && ctx->early_exit && kk <= 254 &&
-                           ctx->k_max <= (int64_t)kMaxPasses * kPass;
     if (use_dense) {
         int rc = launch_dense(ctx, a, grid, n_tiles, N, strided, n_plane_ptrs, tile_chunk, lev2);
         if (rc)
@@ -1515,6 +1549,19 @@ int slot_reserve(wd_ctx::IngestSlot *s, size_t need)
 }
 
 }  // namespace
+
+int wd_interleave4(wd_ctx *ctx, const uint8_t *const src[4], int64_t n_clusters, uint8_t *dst_dev)
+{
+    if (!ctx || !src || !dst_dev || n_clusters < 0)
+        return WD_ERR_ARG;
+    if (bind_device(ctx))
+        return WD_ERR_HIP;
+    if (n_clusters > 0)
+        hipLaunchKernelGGL(k_interleave4, dim3((unsigned)((n_clusters + kBlock - 1) / kBlock)), dim3(kBlock), 0,
+                           ctx->stream, src[0], src[1], src[2], src[3], (long long)n_clusters, (uint32_t *)dst_dev);
+    WD_HIP(ctx, hipGetLastError());
+    return WD_OK;
+}
 
 int wd_gunzip(const uint8_t *src, size_t src_len, uint8_t *dst, size_t dst_cap, size_t *produced, int mode)
 {

@@ -306,21 +306,44 @@ class TileBatch:
     """BCL planes + filter bytes of a list of tiles, resident in HBM.
 
     Layout: planes[tile][cycle][N_pad] and filters[tile][N_pad], N_pad = N rounded up to
-    256 bytes.  Fill with `fill_synthetic` (device generator) or `upload_tile` (host bytes).
+    256 bytes - or, with interleave=4, planes[tile][cycle // 4][N_pad][4]: the four cycles of a
+    group side by side per well (include/welldup.h, wd_interleave4), which the equality /
+    Hamming scan of sampled targets reads in half the cache lines.  Fill with `fill_synthetic`
+    (device generator) or `upload_tile` (host bytes).
     """
 
-    def __init__(self, scanner: Scanner, n_tiles: int, L: int, n_clusters: int):
+    def __init__(self, scanner: Scanner, n_tiles: int, L: int, n_clusters: int, interleave: int = 1):
+        assert interleave in (1, 4)
         self.sc = scanner
         self.n_tiles, self.L, self.N = n_tiles, L, n_clusters
+        self.interleave = interleave
         self.n_pad = (n_clusters + PLANE_ALIGN - 1) // PLANE_ALIGN * PLANE_ALIGN
-        self.plane_bytes = n_tiles * L * self.n_pad
+        self.groups = (L + interleave - 1) // interleave          # plane slots per tile
+        self.slot_bytes = self.n_pad * interleave
+        self.plane_bytes = n_tiles * self.groups * self.slot_bytes
         self.filter_bytes = n_tiles * self.n_pad
         self.d_planes = scanner.malloc(max(1, self.plane_bytes))
         self.d_filters = scanner.malloc(max(1, self.filter_bytes))
+        self.d_tmp = scanner.malloc(4 * self.n_pad) if interleave == 4 else 0
         self.tables = Scanner._tables(self.plane_ptrs(), self.filter_ptrs(), L)
 
     def plane_ptr(self, tile: int, cycle: int) -> int:
-        return self.d_planes + (tile * self.L + cycle) * self.n_pad
+        """Address of well 0 of the cycle (wells are `interleave` bytes apart)."""
+        g, sub = divmod(cycle, self.interleave)
+        return self.d_planes + (tile * self.groups + g) * self.slot_bytes + sub
+
+    def _put_plane(self, tile: int, cycle: int, produce):
+        """produce(dst) writes one plain N-byte plane at dst; lands it in this batch's layout."""
+        if self.interleave == 1:
+            produce(self.plane_ptr(tile, cycle))
+            return
+        sub = cycle % 4
+        produce(self.d_tmp + sub * self.n_pad)
+        if sub == 3 or cycle == self.L - 1:                       # the group is complete
+            src = (ctypes.c_void_p * 4)(*[self.d_tmp + i * self.n_pad if i <= sub else None for i in range(4)])
+            self.sc._ck(self.sc._lib.wd_interleave4(self.sc._ctx, src, self.N,
+                                                    ctypes.c_void_p(self.plane_ptr(tile, cycle - sub))))
+            self.sc.synchronize()                                 # d_tmp is reused by the next group
 
     def filter_ptr(self, tile: int) -> int:
         return self.d_filters + tile * self.n_pad
@@ -338,26 +361,36 @@ class TileBatch:
         for i, (lane, tile) in enumerate(lane_tile):
             self.sc.synth_filter(self.filter_ptr(i), spec, lane, tile)
             for c, cyc in enumerate(cycles):
-                self.sc.synth_plane(self.plane_ptr(i, c), spec, lane, tile, cyc)
+                self._put_plane(i, c, lambda dst, cyc=cyc: self.sc.synth_plane(dst, spec, lane, tile, cyc))
         self.sc.synchronize()
 
     def upload_tile(self, slot: int, planes: Iterable[np.ndarray], filt: np.ndarray):
         for c, p in enumerate(planes):
             assert p.shape[0] == self.N
-            self.sc.h2d(self.plane_ptr(slot, c), np.ascontiguousarray(p, dtype=np.uint8))
+            self._put_plane(slot, c, lambda dst, p=p: self.sc.h2d(dst, np.ascontiguousarray(p, dtype=np.uint8)))
         assert filt.shape[0] == self.N
         self.sc.h2d(self.filter_ptr(slot), np.ascontiguousarray(filt, dtype=np.uint8))
 
     def download_plane(self, slot: int, cycle: int) -> np.ndarray:
-        return self.sc.d2h(self.plane_ptr(slot, cycle), self.N)
+        if self.interleave == 1:
+            return self.sc.d2h(self.plane_ptr(slot, cycle), self.N)
+        g, sub = divmod(cycle, 4)
+        group = self.sc.d2h(self.plane_ptr(slot, 4 * g), 4 * self.N)
+        return np.ascontiguousarray(group[sub::4])
 
     def download_filter(self, slot: int) -> np.ndarray:
         return self.sc.d2h(self.filter_ptr(slot), self.N)
 
     def count(self, mode: int, k: int, per_target: bool = False):
-        return self.sc.count_tiles(None, self.filter_ptrs(), self.N, mode, k, per_target,
-                                   tables=self.tables, L=self.L)
+        self.sc.set_option("well_stride", self.interleave)
+        try:
+            return self.sc.count_tiles(None, self.filter_ptrs(), self.N, mode, k, per_target,
+                                       tables=self.tables, L=self.L)
+        finally:
+            self.sc.set_option("well_stride", 1)
 
     def free(self):
         self.sc.free(self.d_planes)
         self.sc.free(self.d_filters)
+        if self.d_tmp:
+            self.sc.free(self.d_tmp)
