@@ -569,6 +569,17 @@ def test_interleaved_layout_equals_plane_layout(sc, L):
         sc.set_option("dense_kernel", 1)
         with pytest.raises(RuntimeError):
             inter.count(0, 0)
+        sc.set_option("dense_kernel", -1)
+        with pytest.raises(ValueError):                       # only 1 and 4 exist
+            sc.set_option("well_stride", 3)
+        if L > 1:
+            # pointers of a plane-per-cycle batch do not describe an interleaved one
+            sc.set_option("well_stride", 4)
+            try:
+                with pytest.raises(ValueError):
+                    sc.count_tiles(None, plane.filter_ptrs(), spec.n_clusters, 0, 0, tables=plane.tables, L=L)
+            finally:
+                sc.set_option("well_stride", 1)
     finally:
         sc.set_option("dense_kernel", -1)
         plane.free()
