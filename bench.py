@@ -42,8 +42,8 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--tiles", type=int, default=None,
                     help="tiles per rank (one lane); default: all tiles of --stype (96 / 112)")
     ap.add_argument("--stype", default="hiseq_x", choices=["hiseq_x", "hiseq_4000"],
