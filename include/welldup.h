@@ -81,10 +81,15 @@ int wd_synchronize(wd_ctx *ctx);
  * "queue_first" (0 = from k), "batch_first" (4), "batch_next" (4), "profile" (0),
  * "null_stream" (0), "dense_kernel" (-1 = automatic: lane-per-target kernel when T >= 65536),
  * "dense_tile_chunk" (4: tiles that walk a block of targets together in the dense path),
- * "dense_queue_cap" (0 = 128: survivor entries per 256 targets), "dense_pack" (-1 = pack all
- * cycles into rows when the batch has many survivors, 0 = never, 1 = always), "fast_inflate" (1:
+ * "dense_queue_cap" (0 = 128: survivor entries per 256 targets), "dense_pack" (-1 = settle the
+ * survivors on packed rows of the wells they involve whenever there are any, 0 = byte by byte on
+ * the planes, 1 = rows always), "fast_inflate" (1:
  * the loaders try the library's own gunzip before zlib; the environment variable WD_FAST_INFLATE
  * sets the default), "well_stride" (1 = a plane per cycle; 4 = interleaved, see wd_interleave4).
+ * Read-only (wd_get_option; -1 before the first dense scan of the current targets):
+ * "dense_uniform_groups" (64-target groups of consecutive centres that share their neighbour
+ * offsets), "dense_window_groups" (those scanned through signature windows in LDS),
+ * "dense_window_dwords" (LDS dwords per wave of the largest window).
  * Unknown names return WD_ERR_ARG. */
 int wd_set_option(wd_ctx *ctx, const char *name, int64_t value);
 int wd_get_option(wd_ctx *ctx, const char *name, int64_t *value);

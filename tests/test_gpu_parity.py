@@ -406,6 +406,68 @@ def test_dense_all_centres_small(sc):
     tb.free()
 
 
+@pytest.mark.parametrize("L", [150, 24, 17])
+def test_dense_window_groups(sc, L):
+    """A grid wide enough (200 wells per row) that most 64-target groups lie inside one row: the
+    dense path scans them through LDS windows of their neighbours' signatures (k_dense_windows,
+    k_dense_pairs) and settles the survivors on packed rows of the marked wells only.  Every mode
+    and pack setting against the oracle, duplicates planted near and far, per-target counts,
+    tallies and the hit log."""
+    from well_duplicates_amd import workload
+    rows, cols, levels = 30, 200, 3
+    n = rows * cols
+    x, y = synth.honeycomb_pixels(rows, cols)
+    centre, lvl_off, nbr = workload.targets_to_csr(cluster_indexes.generate(x, y, range(n), levels))
+    spec = synth.SynthSpec(seed=21 + L, n_clusters=n, row=cols, plant_per_64k=3000, plant_far=True,
+                           nocall_per_64k=1500)
+    sc.set_targets(centre, lvl_off, nbr)
+    tiles = [(1, 1101), (2, 1205), (3, 2101)]
+    tb = TileBatch(sc, len(tiles), L, n)
+    tb.fill_synthetic(spec, tiles, list(range(L)))
+    host = [([synth.plane_bytes(spec, lane, tile, c) for c in range(L)],
+             synth.filter_bytes(spec, lane, tile)) for lane, tile in tiles]
+    try:
+        for mode, k, pack in ((0, 0, -1), (0, 0, 0), (1, 1, -1), (1, 2, 1), (1, 2, 0), (2, 2, -1), (2, 2, 0)):
+            sc.set_option("dense_kernel", 1)
+            sc.set_option("dense_pack", pack)
+            sc.hitlog_enable(400000)
+            blocks, pt = tb.count(mode, k, per_target=True)
+            hits, total = sc.hitlog_fetch(400000)
+            sc.hitlog_enable(0)
+            groups = (n + 63) // 64
+            assert sc.get_option("dense_window_groups") > groups // 4        # the path under test ran
+            assert sc.get_option("dense_window_groups") < groups             # and so did the gather path
+            want_hits = []
+            for i in range(len(tiles)):
+                planes, filt = host[i]
+                valid, dups, lens, dist = oracle.count_tile(planes, filt, centre, lvl_off, nbr, mode, k, want_dist=True)
+                got = pt[i].astype(np.int64)
+                got[got == INVALID_TARGET] = -1
+                assert (got == np.where(valid[:, None] == 1, dups, -1)).all(), (L, mode, k, pack)
+                assert (blocks_to_reference(blocks[i], levels) == oracle.tally_tile(valid, dups, lens)).all()
+                kk = 0 if mode == 0 else k
+                slots = np.arange(nbr.shape[0])
+                tgt = np.searchsorted(lvl_off[:, 0], slots, side="right") - 1
+                ok = (valid[tgt] == 1) & (slots < lvl_off[tgt, -1]) & (dist <= kk)
+                want_hits += [(i, int(t), int(p), int(dist[p])) for t, p in zip(tgt[ok], slots[ok])]
+            assert total == len(want_hits) > 0
+            assert sorted((int(h["tile"]), int(h["target"]), int(h["slot"]), int(h["dist"])) for h in hits) \
+                == sorted(want_hits)
+        # a survivor queue far too small: the overflow paths (finish in place / leave the block to
+        # k_dense_verify with every well of the block marked)
+        for mode, k in ((0, 0), (1, 2), (2, 2)):
+            want = tb.count(mode, k, per_target=True)
+            sc.set_option("dense_queue_cap", 3)
+            got = tb.count(mode, k, per_target=True)
+            sc.set_option("dense_queue_cap", 0)
+            assert (got[0] == want[0]).all() and (got[1] == want[1]).all(), (L, mode, k)
+    finally:
+        sc.set_option("dense_kernel", -1)
+        sc.set_option("dense_pack", -1)
+        sc.set_option("dense_queue_cap", 0)
+        tb.free()
+
+
 @pytest.mark.parametrize("L", [1, 3, 5, 6, 9])
 def test_dense_short_reads(sc, L):
     """Reads no longer than the 5-cycle signature never reach the verify kernel; low diversity

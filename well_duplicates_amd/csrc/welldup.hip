@@ -135,8 +135,10 @@ struct wd_ctx {
     size_t qcnt_cap = 0;
     long long dense_queue_cap = 0;             // option: entries per 256-target block; 0 = from k
     uint32_t *d_cand = nullptr;                // dense path: survivor counts of the batch (kDenseSlots)
-    uint4 *d_rows = nullptr;                   // dense path: packed cycles [n_tiles][kRowGroups][N]
+    uint4 *d_rows = nullptr;                   // dense path: packed cycles of the marked wells [n_tiles][N][kRowGroups]
     size_t rows_cap = 0;       // uint4 elements
+    uint32_t *d_mark = nullptr;                // dense path: [3][n_tiles][mw_stride]: mark bits, word prefixes, block prefixes
+    size_t mark_cap = 0;       // words
     int dense_pack = -1;                       // option: -1 = by survivor count, 0 = never, 1 = always
     int fast_inflate = 1;                      // option: own gunzip first, zlib as referee (0 = zlib only)
     int well_stride = 1;                       // option: 1 = a plane per cycle, 4 = cycles interleaved by four
@@ -154,7 +156,13 @@ struct wd_ctx {
     bool nbr_t16 = false;
     int32_t *d_rel_t = nullptr;       // dense path: ring ends per target, level-major
     void *d_udelta = nullptr;         // dense path: shared neighbour offsets of uniform groups (type of d_nbr_t)
-    uint8_t *d_guni = nullptr;        // dense path: which groups are uniform
+    uint8_t *d_guni = nullptr;        // dense path: which groups are uniform (1 + runs of their LDS window)
+    uint16_t *d_uoff = nullptr;       // dense path: window groups: a neighbour's place in the wave's LDS window
+    int2 *d_useg = nullptr;           // dense path: window groups: the runs of the window
+    int win_kpad = 0;                 // row length of d_uoff
+    int win_dwords = 0;               // largest window of any group, in dwords
+    long long n_uniform_groups = -1, n_window_groups = -1;   // -1: tables not built yet
+    uint32_t *d_tblflags = nullptr;   // scratch of the table builders: [0] offsets need 32 bits, [1] largest window
     long long *d_gbase = nullptr;
     bool has_targets = false;
     bool has_empty_level = false;
@@ -343,8 +351,14 @@ void set_group_bases(wd_ctx *ctx, const int32_t *lvl_off, int T, int levels)
     (void)hipFree(ctx->d_rel_t);
     (void)hipFree(ctx->d_udelta);
     (void)hipFree(ctx->d_guni);
+    (void)hipFree(ctx->d_uoff);
+    (void)hipFree(ctx->d_useg);
     ctx->d_udelta = nullptr;
     ctx->d_guni = nullptr;
+    ctx->d_uoff = nullptr;
+    ctx->d_useg = nullptr;
+    ctx->win_kpad = ctx->win_dwords = 0;
+    ctx->n_uniform_groups = ctx->n_window_groups = -1;
     ctx->d_nbr_t = nullptr;
     ctx->d_gbase = nullptr;
     ctx->d_rel_t = nullptr;
@@ -370,27 +384,55 @@ int ensure_dense_tables(wd_ctx *ctx)
     const size_t n_el = (size_t)std::max<long long>(1, total);
     WD_HIP(ctx, hipMalloc(&ctx->d_nbr_t, n_el * sizeof(int16_t)));
     ctx->nbr_t16 = true;
+    if (!ctx->d_tblflags)
+        WD_HIP(ctx, hipMalloc((void **)&ctx->d_tblflags, 2 * sizeof(uint32_t)));
     if (groups > 0) {
-        WD_HIP(ctx, hipMemsetAsync(ctx->d_status, 0, sizeof(uint32_t), ctx->stream));
+        uint32_t flags[2] = {0, 0};
+        WD_HIP(ctx, hipMemsetAsync(ctx->d_tblflags, 0, sizeof(flags), ctx->stream));
         hipLaunchKernelGGL((k_transpose_nbr<int16_t>), dim3(groups), dim3(kWave), 0, ctx->stream, ctx->d_centre,
                            ctx->d_lvl_off, ctx->d_nbr, ctx->d_gbase, (int16_t *)ctx->d_nbr_t, ctx->T, ctx->levels,
-                           ctx->d_status, (int16_t *)ctx->d_udelta, ctx->d_guni);
-        uint32_t wide = 0;
-        WD_HIP(ctx, hipMemcpyAsync(&wide, ctx->d_status, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+                           ctx->d_tblflags, (int16_t *)ctx->d_udelta, ctx->d_guni);
+        WD_HIP(ctx, hipMemcpyAsync(flags, ctx->d_tblflags, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
         WD_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        WD_HIP(ctx, hipMemsetAsync(ctx->d_status, 0, sizeof(uint32_t), ctx->stream));
-        if (wide) {
+        if (flags[0]) {
             (void)hipFree(ctx->d_nbr_t);
             ctx->d_nbr_t = nullptr;
             ctx->nbr_t16 = false;
             WD_HIP(ctx, hipMalloc(&ctx->d_nbr_t, n_el * sizeof(int32_t)));
             hipLaunchKernelGGL((k_transpose_nbr<int32_t>), dim3(groups), dim3(kWave), 0, ctx->stream, ctx->d_centre,
                                ctx->d_lvl_off, ctx->d_nbr, ctx->d_gbase, (int32_t *)ctx->d_nbr_t, ctx->T,
-                               ctx->levels, ctx->d_status, (int32_t *)ctx->d_udelta, ctx->d_guni);
+                               ctx->levels, ctx->d_tblflags, (int32_t *)ctx->d_udelta, ctx->d_guni);
+        }
+        // uniform groups whose neighbours fall into a few runs: LDS windows (k_dense_windows)
+        if (ctx->k_max >= 1 && ctx->k_max <= kWinMaxK) {
+            ctx->win_kpad = (int)((ctx->k_max + 7) & ~(int64_t)7);
+            WD_HIP(ctx, hipMalloc((void **)&ctx->d_uoff, (size_t)groups * ctx->win_kpad * sizeof(uint16_t)));
+            WD_HIP(ctx, hipMalloc((void **)&ctx->d_useg, (size_t)groups * kMaxSeg * sizeof(int2)));
+            if (ctx->nbr_t16)
+                hipLaunchKernelGGL((k_dense_windows<int16_t>), dim3(groups), dim3(kWave), 0, ctx->stream, ctx->d_gbase,
+                                   (const int16_t *)ctx->d_udelta, ctx->d_guni, ctx->d_uoff, ctx->win_kpad, ctx->d_useg,
+                                   ctx->d_tblflags + 1);
+            else
+                hipLaunchKernelGGL((k_dense_windows<int32_t>), dim3(groups), dim3(kWave), 0, ctx->stream, ctx->d_gbase,
+                                   (const int32_t *)ctx->d_udelta, ctx->d_guni, ctx->d_uoff, ctx->win_kpad, ctx->d_useg,
+                                   ctx->d_tblflags + 1);
+            WD_HIP(ctx, hipMemcpyAsync(flags, ctx->d_tblflags, sizeof(flags), hipMemcpyDeviceToHost, ctx->stream));
+            WD_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            ctx->win_dwords = (int)((flags[1] + 1u) & ~1u);               // the queue behind the windows stays 8-byte aligned
         }
     }
     WD_HIP(ctx, hipGetLastError());
     WD_HIP(ctx, hipStreamSynchronize(ctx->stream));       // h_gbase may be reused by the caller
+    {
+        std::vector<uint8_t> guni((size_t)groups);
+        if (groups > 0)
+            WD_HIP(ctx, hipMemcpy(guni.data(), ctx->d_guni, (size_t)groups, hipMemcpyDeviceToHost));
+        ctx->n_uniform_groups = ctx->n_window_groups = 0;
+        for (uint8_t v : guni) {
+            ctx->n_uniform_groups += v != 0;
+            ctx->n_window_groups += v >= 2;
+        }
+    }
     return WD_OK;
 }
 
@@ -459,6 +501,10 @@ int launch_dense(wd_ctx *ctx, const ScanArgs &a, dim3 grid, int n_tiles, int64_t
     d.rel_t = ctx->d_rel_t;
     d.udelta = ctx->d_udelta;
     d.guni = ctx->d_guni;
+    d.uoff = ctx->d_uoff;
+    d.useg = ctx->d_useg;
+    d.kpad = ctx->win_kpad;
+    d.win_dwords = ctx->win_dwords;
     d.gbase = ctx->d_gbase;
     d.out_per_target = a.out_per_target;
     d.rare = a.rare;
@@ -482,16 +528,24 @@ int launch_dense(wd_ctx *ctx, const ScanArgs &a, dim3 grid, int n_tiles, int64_t
     // for Levenshtein, by k_dense_verify): a speed knob, not a limit
     const long long regions = (long long)n_tiles * ((a.T + kBlock - 1) / kBlock);
     long long q_per = ctx->dense_queue_cap > 0 ? ctx->dense_queue_cap : 128;
-    q_per = std::max<long long>(1, std::min<long long>(q_per, 7168));     // LDS: 8 bytes each
+    // LDS of a k_dense_pairs block: the four waves' signature windows, then 8 bytes per queue entry
+    const long long win_bytes = (long long)kWaves * d.win_dwords * sizeof(uint32_t);
+    q_per = std::max<long long>(1, std::min<long long>(q_per, (64 * 1024 - 256 - win_bytes) / 8));
     d.q_per = (int)q_per;
+    d.mw_stride = (((N + 31) / 32) + kMarkBlock - 1) / kMarkBlock * kMarkBlock;
+    const size_t mark_words = (size_t)n_tiles * d.mw_stride;
     const size_t part_need = (size_t)n_tiles * kDenseSlots * d.partial_stride;
     const size_t mask_need = (size_t)n_tiles * d.mask_stride;
     if ((rc = dense_reserve(ctx, ctx->d_sig, ctx->sig_cap, (size_t)d.sig_stride * n_tiles * (lev2 ? 2 : 1), "signature planes")) ||
         (rc = dense_reserve(ctx, ctx->d_partial, ctx->partial_cap, part_need, "counter slots")) ||
         (rc = dense_reserve(ctx, ctx->d_mask, ctx->mask_cap, mask_need, "hit masks")) ||
         (rc = dense_reserve(ctx, ctx->d_queue, ctx->queue_cap, (size_t)(regions * q_per), "survivor queue")) ||
-        (rc = dense_reserve(ctx, ctx->d_qcnt, ctx->qcnt_cap, (size_t)regions, "survivor counts")))
+        (rc = dense_reserve(ctx, ctx->d_qcnt, ctx->qcnt_cap, (size_t)regions, "survivor counts")) ||
+        (rc = dense_reserve(ctx, ctx->d_mark, ctx->mark_cap, 3 * mark_words, "marked wells")))
         return rc;
+    d.mark = ctx->d_mark;
+    d.wprefix = ctx->d_mark + mark_words;
+    d.bprefix = ctx->d_mark + 2 * mark_words;
     if (!ctx->d_cand)
         WD_HIP(ctx, hipMalloc((void **)&ctx->d_cand, (kDenseSlots + 1) * sizeof(uint32_t)));
     // packed rows are optional scratch (64 bytes per well): without them every survivor is
@@ -505,11 +559,11 @@ int launch_dense(wd_ctx *ctx, const ScanArgs &a, dim3 grid, int n_tiles, int64_t
         d.rows = ctx->d_rows;
     if (lev2 && a.L > d.sig_cycles && !d.rows)               // (the caller reserved them)
         return fail(ctx, WD_ERR_NOMEM, "packed rows");
-    // Checking one survivor against the planes touches ~2 (L - 10) cache lines (measured: 2.7 ns
-    // per duplicate record at 150 bp, HBM line rate); packing streams every plane once and
-    // writes 64 bytes per well (measured: 0.2 ms per 4.3 M-well tile).  Break-even is at about
-    // one record per 8192 plane bytes.
-    d.pack_threshold = std::max<long long>(1, (long long)n_tiles * N * a.L / 8192);
+    // Checking one survivor against the planes touches 2 (L - 10) cache lines, one per plane and
+    // well; packing touches at most one line per plane and MARKED well (wells of a line share it,
+    // lines without a marked well are skipped) and leaves a 64-byte row per marked well: never
+    // more lines than the byte-by-byte check, so rows are used whenever there is a survivor.
+    d.pack_threshold = 1;
     d.cand = ctx->d_cand;
     WD_HIP(ctx, hipMemsetAsync(ctx->d_cand, 0, (kDenseSlots + 1) * sizeof(uint32_t), ctx->stream));
     d.sig = ctx->d_sig;
@@ -520,6 +574,8 @@ int launch_dense(wd_ctx *ctx, const ScanArgs &a, dim3 grid, int n_tiles, int64_t
     d.q_cnt = ctx->d_qcnt;
     WD_HIP(ctx, hipMemsetAsync(ctx->d_partial, 0, part_need * sizeof(unsigned long long), ctx->stream));
     WD_HIP(ctx, hipMemsetAsync(ctx->d_mask, 0, mask_need * sizeof(uint32_t), ctx->stream));
+    if (d.rows)
+        WD_HIP(ctx, hipMemsetAsync(ctx->d_mark, 0, mark_words * sizeof(uint32_t), ctx->stream));
 
     // dword loads in k_dense_sig need every plane 4-byte aligned
     bool aligned4 = (a.stride & 3) == 0;
@@ -535,7 +591,7 @@ int launch_dense(wd_ctx *ctx, const ScanArgs &a, dim3 grid, int n_tiles, int64_t
         hipLaunchKernelGGL((k_dense_sig<false, true>), grid1, dim3(kBlock), 0, ctx->stream, d);
     else
         hipLaunchKernelGGL((k_dense_sig<false, false>), grid1, dim3(kBlock), 0, ctx->stream, d);
-    const size_t q_lds = (size_t)d.q_per * sizeof(uint2);
+    const size_t q_lds = (size_t)win_bytes + (size_t)d.q_per * sizeof(uint2);
     const int pmode = lev2 ? 2 : (a.k == 0 ? 0 : 1);
 #define WD_LAUNCH_PAIRS(MODE)                                                                            \
     do {                                                                                                 \
@@ -552,6 +608,9 @@ int launch_dense(wd_ctx *ctx, const ScanArgs &a, dim3 grid, int n_tiles, int64_t
         WD_LAUNCH_PAIRS(2);
 #undef WD_LAUNCH_PAIRS
     if (d.rows) {
+        hipLaunchKernelGGL(k_dense_rank_words, dim3((unsigned)(d.mw_stride / kMarkBlock), (unsigned)n_tiles), dim3(kMarkBlock),
+                           0, ctx->stream, d);
+        hipLaunchKernelGGL(k_dense_rank_blocks, dim3((unsigned)n_tiles), dim3(1024), 0, ctx->stream, d);
         if (aligned4 && strided)
             hipLaunchKernelGGL((k_dense_pack<4, true>), grid4, dim3(kBlock), 0, ctx->stream, d);
         else if (aligned4)
@@ -674,6 +733,10 @@ void wd_destroy(wd_ctx *ctx)
     (void)hipFree(ctx->d_rel_t);
     (void)hipFree(ctx->d_udelta);
     (void)hipFree(ctx->d_guni);
+    (void)hipFree(ctx->d_uoff);
+    (void)hipFree(ctx->d_useg);
+    (void)hipFree(ctx->d_tblflags);
+    (void)hipFree(ctx->d_mark);
     (void)hipFree(ctx->d_sig);
     (void)hipFree(ctx->d_partial);
     (void)hipFree(ctx->d_mask);
@@ -796,6 +859,11 @@ int wd_get_option(wd_ctx *ctx, const char *name, int64_t *value)
     else if (n == "well_stride") *value = ctx->well_stride;
     else if (n == "null_stream") *value = ctx->stream == nullptr ? 1 : 0;
     else if (n == "queue_first") *value = ctx->queue_first;
+    // read-only, -1 before the first dense scan of the current targets: 64-target groups of
+    // consecutive centres with common neighbour offsets, and those scanned through LDS windows
+    else if (n == "dense_uniform_groups") *value = ctx->n_uniform_groups;
+    else if (n == "dense_window_groups") *value = ctx->n_window_groups;
+    else if (n == "dense_window_dwords") *value = ctx->win_dwords;
     else return fail(ctx, WD_ERR_ARG, "unknown option " + n);
     return WD_OK;
 }
