@@ -80,10 +80,11 @@ int wd_synchronize(wd_ctx *ctx);
 /* Tunables, by name (default): "early_exit" (1), "targets_per_block" (64), "queue_kernel" (1),
  * "queue_first" (0 = from k), "batch_first" (4), "batch_next" (4), "profile" (0),
  * "null_stream" (0), "dense_kernel" (-1 = automatic: lane-per-target kernel when T >= 65536),
- * "dense_tile_chunk" (4: tiles that walk a block of targets together in the dense path),
- * "dense_queue_cap" (0 = 128: survivor entries per 256 targets), "dense_pack" (-1 = settle the
+ * "dense_tile_chunk" (8: tiles one wave takes a group of 64 targets through in the dense path),
+ * "dense_queue_cap" (0 = 16, 32 for Levenshtein: survivor entries per 64 targets), "dense_pack" (-1 = settle the
  * survivors on packed rows of the wells they involve whenever there are any, 0 = byte by byte on
- * the planes, 1 = rows always), "fast_inflate" (1:
+ * the planes, 1 = rows always), "dense_windows" (1: groups of consecutive centres compare their
+ * neighbours' signatures from LDS windows; 0 = every group gathers them through L1), "fast_inflate" (1:
  * the loaders try the library's own gunzip before zlib; the environment variable WD_FAST_INFLATE
  * sets the default), "well_stride" (1 = a plane per cycle; 4 = interleaved, see wd_interleave4).
  * Read-only (wd_get_option; -1 before the first dense scan of the current targets):

@@ -110,3 +110,25 @@ def test_levenshtein_le2_closed_form(data):
     if oracle.py_levenshtein(a, b) <= 2:
         for cut in range(1, n):
             assert _lev2_equal_length(a[:cut], b[:cut]) <= 2
+    # the screen of the dense compare stage (csrc/scan_dense.inc: lev2_screen, on the first 16
+    # cycles, 2 bits each, a no-call reading as A) never rejects a pair within distance 2
+    if oracle.py_levenshtein(a, b) <= 2:
+        for cut in (min(n, 16), min(n, 7), 1):
+            assert _lev2_screen(_screen_word(a[:cut]), _screen_word(b[:cut])) <= 1, (a[:cut], b[:cut])
+
+
+def _screen_word(s: str) -> int:
+    """k_dense_sig's screen word: byte & 3 per cycle (A, C, G, T = 0..3; a no-call, byte 0, reads
+    as A), 2 bits each; unused high fields are 0."""
+    return sum(("ACGTN".index(ch) & 3 if ch != "N" else 0) << (2 * i) for i, ch in enumerate(s))
+
+
+def _lev2_screen(a: int, b: int) -> int:
+    """csrc/scan_dense.inc lev2_screen on 32-bit words."""
+    ah, al = a >> 2, (a << 2) & 0xFFFFFFFF
+    fold = lambda x: (x | (x >> 1))
+    m0 = fold(a ^ b) & 0x55555555
+    up = fold(ah ^ b) & m0
+    dn = fold(al ^ b) & m0
+    pop = lambda v: bin(v).count("1")
+    return min((pop(m0) + 1) >> 1, pop(up), pop(dn))

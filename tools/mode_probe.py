@@ -84,7 +84,12 @@ def main():
     else:
         b_alg = C * (L + 4) + Tv * (L + 5) + 8 * ncnt * tiles
     ms /= max(1, cnt)
-    print(json.dumps({"case": a.case, "workload": "dense" if a.case in DENSE else a.workload, "tiles": tiles,
+    extra = {}
+    if a.case in DENSE:
+        extra = {"groups": (T + 63) // 64, "uniform_groups": sc.get_option("dense_uniform_groups"),
+                 "window_groups": sc.get_option("dense_window_groups"),
+                 "window_dwords": sc.get_option("dense_window_dwords")}
+    print(json.dumps({**extra, "case": a.case, "workload": "dense" if a.case in DENSE else a.workload, "tiles": tiles,
                       "T": T, "levels": levels, "L": L, "mode": mode, "k": k, "plant_per_64k": spec.plant_per_64k,
                       "scans_timed": cnt, "kernel_ms": round(ms, 5), "compares": C, "valid_targets": Tv,
                       "duplicates": int(blk[:, 1 + levels:1 + 2 * levels].sum()),

@@ -122,7 +122,7 @@ struct wd_ctx {
     int queue_kernel = 1;      // equality / Hamming with early exit: use k_scan_q
     int queue_first = 0;       // cycles of its first round; 0 = choose from k
     int dense_kernel = -1;     // lane-per-target kernel: -1 = when the targets look dense
-    int dense_tile_chunk = 4;  // dense kernel: tiles that share a target block's index lines in L2
+    int dense_tile_chunk = 8;  // dense kernel: tiles a group of targets is taken through by one wave
     uint32_t *d_sig = nullptr; // dense path: signature planes [n_tiles][sig_stride]
     size_t sig_cap = 0;        // elements
     unsigned long long *d_partial = nullptr;   // dense path: counter slots [n_tiles][kDenseSlots][stride]
@@ -140,6 +140,7 @@ struct wd_ctx {
     uint32_t *d_mark = nullptr;                // dense path: [3][n_tiles][mw_stride]: mark bits, word prefixes, block prefixes
     size_t mark_cap = 0;       // words
     int dense_pack = -1;                       // option: -1 = by survivor count, 0 = never, 1 = always
+    int dense_windows = 1;                     // option: 0 = no LDS windows, every group gathers through L1
     int fast_inflate = 1;                      // option: own gunzip first, zlib as referee (0 = zlib only)
     int well_stride = 1;                       // option: 1 = a plane per cycle, 4 = cycles interleaved by four
     int profile = 0;           // HIP events around every n-th scan (0 = off)
@@ -156,10 +157,14 @@ struct wd_ctx {
     bool nbr_t16 = false;
     int32_t *d_rel_t = nullptr;       // dense path: ring ends per target, level-major
     void *d_udelta = nullptr;         // dense path: shared neighbour offsets of uniform groups (type of d_nbr_t)
-    uint8_t *d_guni = nullptr;        // dense path: which groups are uniform (1 + runs of their LDS window)
-    uint16_t *d_uoff = nullptr;       // dense path: window groups: a neighbour's place in the wave's LDS window
-    int2 *d_useg = nullptr;           // dense path: window groups: the runs of the window
-    int win_kpad = 0;                 // row length of d_uoff
+    uint8_t *d_guni = nullptr;        // dense path: which groups are uniform
+    int32_t *d_ginfo = nullptr;       // dense path: window groups (k_dense_windows): union size | runs << 9
+    uint16_t *d_uoff = nullptr;       // ... a union element's place in the wave's LDS window
+    int2 *d_useg = nullptr;           // ... the runs of the window
+    int32_t *d_wdelta = nullptr;      // ... the union's offsets
+    uint8_t *d_wlev = nullptr;        // ... and rings
+    uint32_t *d_wmask = nullptr;      // ... which elements each target has
+    int win_kpad = 0;                 // row length of d_uoff / d_wdelta
     int win_dwords = 0;               // largest window of any group, in dwords
     long long n_uniform_groups = -1, n_window_groups = -1;   // -1: tables not built yet
     uint32_t *d_tblflags = nullptr;   // scratch of the table builders: [0] offsets need 32 bits, [1] largest window
@@ -351,12 +356,20 @@ void set_group_bases(wd_ctx *ctx, const int32_t *lvl_off, int T, int levels)
     (void)hipFree(ctx->d_rel_t);
     (void)hipFree(ctx->d_udelta);
     (void)hipFree(ctx->d_guni);
+    (void)hipFree(ctx->d_ginfo);
     (void)hipFree(ctx->d_uoff);
     (void)hipFree(ctx->d_useg);
+    (void)hipFree(ctx->d_wdelta);
+    (void)hipFree(ctx->d_wlev);
+    (void)hipFree(ctx->d_wmask);
+    ctx->d_wlev = nullptr;
     ctx->d_udelta = nullptr;
     ctx->d_guni = nullptr;
+    ctx->d_ginfo = nullptr;
     ctx->d_uoff = nullptr;
     ctx->d_useg = nullptr;
+    ctx->d_wdelta = nullptr;
+    ctx->d_wmask = nullptr;
     ctx->win_kpad = ctx->win_dwords = 0;
     ctx->n_uniform_groups = ctx->n_window_groups = -1;
     ctx->d_nbr_t = nullptr;
@@ -403,34 +416,40 @@ int ensure_dense_tables(wd_ctx *ctx)
                                ctx->d_lvl_off, ctx->d_nbr, ctx->d_gbase, (int32_t *)ctx->d_nbr_t, ctx->T,
                                ctx->levels, ctx->d_tblflags, (int32_t *)ctx->d_udelta, ctx->d_guni);
         }
-        // uniform groups whose neighbours fall into a few runs: LDS windows (k_dense_windows)
-        if (ctx->k_max >= 1 && ctx->k_max <= kWinMaxK) {
-            ctx->win_kpad = (int)((ctx->k_max + 7) & ~(int64_t)7);
-            WD_HIP(ctx, hipMalloc((void **)&ctx->d_uoff, (size_t)groups * ctx->win_kpad * sizeof(uint16_t)));
+        // groups of consecutive centres whose neighbours fall into a few runs of offsets: LDS
+        // windows (k_dense_windows); the union of a group's offsets may be a little larger than
+        // any one target's list
+        const int64_t kpad = std::min<int64_t>(kWinMaxK, (ctx->k_max + ctx->k_max / 2 + 8 + 31) & ~(int64_t)31);
+        if (ctx->k_max >= 1 && ctx->k_max <= kpad) {
+            ctx->win_kpad = (int)kpad;
+            WD_HIP(ctx, hipMalloc((void **)&ctx->d_ginfo, (size_t)groups * sizeof(int32_t)));
+            WD_HIP(ctx, hipMalloc((void **)&ctx->d_uoff, (size_t)groups * kpad * sizeof(uint16_t)));
             WD_HIP(ctx, hipMalloc((void **)&ctx->d_useg, (size_t)groups * kMaxSeg * sizeof(int2)));
-            if (ctx->nbr_t16)
-                hipLaunchKernelGGL((k_dense_windows<int16_t>), dim3(groups), dim3(kWave), 0, ctx->stream, ctx->d_gbase,
-                                   (const int16_t *)ctx->d_udelta, ctx->d_guni, ctx->d_uoff, ctx->win_kpad, ctx->d_useg,
-                                   ctx->d_tblflags + 1);
-            else
-                hipLaunchKernelGGL((k_dense_windows<int32_t>), dim3(groups), dim3(kWave), 0, ctx->stream, ctx->d_gbase,
-                                   (const int32_t *)ctx->d_udelta, ctx->d_guni, ctx->d_uoff, ctx->win_kpad, ctx->d_useg,
-                                   ctx->d_tblflags + 1);
+            WD_HIP(ctx, hipMalloc((void **)&ctx->d_wdelta, (size_t)groups * kpad * sizeof(int32_t)));
+            WD_HIP(ctx, hipMalloc((void **)&ctx->d_wlev, (size_t)groups * kpad));
+            WD_HIP(ctx, hipMalloc((void **)&ctx->d_wmask, (size_t)groups * (kpad / 32) * kWave * sizeof(uint32_t)));
+            WD_HIP(ctx, hipMemsetAsync(ctx->d_ginfo, 0, (size_t)groups * sizeof(int32_t), ctx->stream));
+            hipLaunchKernelGGL(k_dense_windows, dim3(groups), dim3(kWave), 0, ctx->stream, ctx->d_centre, ctx->d_lvl_off,
+                               ctx->d_nbr, ctx->T, ctx->levels, ctx->win_kpad, ctx->d_ginfo, ctx->d_useg, ctx->d_uoff,
+                               ctx->d_wdelta, ctx->d_wlev, ctx->d_wmask, ctx->d_tblflags + 1);
             WD_HIP(ctx, hipMemcpyAsync(flags, ctx->d_tblflags, sizeof(flags), hipMemcpyDeviceToHost, ctx->stream));
             WD_HIP(ctx, hipStreamSynchronize(ctx->stream));
-            ctx->win_dwords = (int)((flags[1] + 1u) & ~1u);               // the queue behind the windows stays 8-byte aligned
+            ctx->win_dwords = (int)((flags[1] + kWave - 1) / kWave * kWave);     // whole pieces of 64 dwords
         }
     }
     WD_HIP(ctx, hipGetLastError());
     WD_HIP(ctx, hipStreamSynchronize(ctx->stream));       // h_gbase may be reused by the caller
     {
         std::vector<uint8_t> guni((size_t)groups);
+        std::vector<int32_t> ginfo((size_t)groups, 0);
         if (groups > 0)
             WD_HIP(ctx, hipMemcpy(guni.data(), ctx->d_guni, (size_t)groups, hipMemcpyDeviceToHost));
+        if (groups > 0 && ctx->d_ginfo)
+            WD_HIP(ctx, hipMemcpy(ginfo.data(), ctx->d_ginfo, (size_t)groups * sizeof(int32_t), hipMemcpyDeviceToHost));
         ctx->n_uniform_groups = ctx->n_window_groups = 0;
-        for (uint8_t v : guni) {
-            ctx->n_uniform_groups += v != 0;
-            ctx->n_window_groups += v >= 2;
+        for (int g = 0; g < groups; g++) {
+            ctx->n_uniform_groups += guni[g] != 0;
+            ctx->n_window_groups += ginfo[g] != 0;
         }
     }
     return WD_OK;
@@ -501,8 +520,12 @@ int launch_dense(wd_ctx *ctx, const ScanArgs &a, dim3 grid, int n_tiles, int64_t
     d.rel_t = ctx->d_rel_t;
     d.udelta = ctx->d_udelta;
     d.guni = ctx->d_guni;
+    d.ginfo = ctx->dense_windows ? ctx->d_ginfo : nullptr;
     d.uoff = ctx->d_uoff;
     d.useg = ctx->d_useg;
+    d.wdelta = ctx->d_wdelta;
+    d.wlev = ctx->d_wlev;
+    d.wmask = ctx->d_wmask;
     d.kpad = ctx->win_kpad;
     d.win_dwords = ctx->win_dwords;
     d.gbase = ctx->d_gbase;
@@ -522,15 +545,16 @@ int launch_dense(wd_ctx *ctx, const ScanArgs &a, dim3 grid, int n_tiles, int64_t
     d.sig_stride = (N + 127) & ~(long long)127;
     d.partial_stride = ((1 + 5 * a.levels) + 15) & ~15;              // whole 128-byte lines per slot
     d.mask_stride = (((long long)a.T + 3) / 4 + 31) & ~31ll;
-    // survivors per block of 256 targets: on diverse reads almost nobody passes 10 cycles (36 x
-    // P(<= 2 mismatches in 10) = 0.015 per target; ~8 per block for Levenshtein <= 2), so the
+    // survivors per group of 64 targets: on diverse reads almost nobody passes 10 cycles (36 x
+    // P(<= 2 mismatches in 10) = 0.015 per target; ~2 per group for Levenshtein <= 2), so the
     // region holds mostly duplicate pairs; what does not fit is finished inside k_dense_pairs (or,
     // for Levenshtein, by k_dense_verify): a speed knob, not a limit
-    const long long regions = (long long)n_tiles * ((a.T + kBlock - 1) / kBlock);
-    long long q_per = ctx->dense_queue_cap > 0 ? ctx->dense_queue_cap : 128;
-    // LDS of a k_dense_pairs block: the four waves' signature windows, then 8 bytes per queue entry
-    const long long win_bytes = (long long)kWaves * d.win_dwords * sizeof(uint32_t);
-    q_per = std::max<long long>(1, std::min<long long>(q_per, (64 * 1024 - 256 - win_bytes) / 8));
+    const long long n_groups = (a.T + kWave - 1) / kWave;
+    const long long regions = (long long)n_tiles * n_groups;
+    long long q_per = ctx->dense_queue_cap > 0 ? ctx->dense_queue_cap : (lev2 ? 32 : 16);
+    // LDS of a k_dense_pairs wave: its signature windows, then 8 bytes per queue entry
+    const long long win_bytes = (long long)kWinBufs * d.win_dwords * sizeof(uint32_t);
+    q_per = std::max<long long>(1, std::min<long long>(q_per, ((64 * 1024 - 256) / kWaves - win_bytes) / 8));
     d.q_per = (int)q_per;
     d.mw_stride = (((N + 31) / 32) + kMarkBlock - 1) / kMarkBlock * kMarkBlock;
     const size_t mark_words = (size_t)n_tiles * d.mw_stride;
@@ -567,7 +591,7 @@ int launch_dense(wd_ctx *ctx, const ScanArgs &a, dim3 grid, int n_tiles, int64_t
     d.cand = ctx->d_cand;
     WD_HIP(ctx, hipMemsetAsync(ctx->d_cand, 0, (kDenseSlots + 1) * sizeof(uint32_t), ctx->stream));
     d.sig = ctx->d_sig;
-    d.sig2 = (lev2 && a.L > kSigCycles) ? ctx->d_sig + (size_t)d.sig_stride * n_tiles : nullptr;
+    d.sig2 = lev2 ? ctx->d_sig + (size_t)d.sig_stride * n_tiles : nullptr;     // Levenshtein: the screen words
     d.partial = ctx->d_partial;
     d.mask = ctx->d_mask;
     d.queue = ctx->d_queue;
@@ -591,14 +615,21 @@ int launch_dense(wd_ctx *ctx, const ScanArgs &a, dim3 grid, int n_tiles, int64_t
         hipLaunchKernelGGL((k_dense_sig<false, true>), grid1, dim3(kBlock), 0, ctx->stream, d);
     else
         hipLaunchKernelGGL((k_dense_sig<false, false>), grid1, dim3(kBlock), 0, ctx->stream, d);
-    const size_t q_lds = (size_t)win_bytes + (size_t)d.q_per * sizeof(uint2);
+    const size_t q_lds = (size_t)kWaves * ((size_t)win_bytes + (size_t)d.q_per * sizeof(uint2));
+    hipLaunchKernelGGL(k_dense_counts, dim3((unsigned)((a.T + 4 * kBlock - 1) / (4 * kBlock)),
+                                            (unsigned)((n_tiles + tile_chunk - 1) / tile_chunk)),
+                       dim3(kBlock), 0, ctx->stream, d);
     const int pmode = lev2 ? 2 : (a.k == 0 ? 0 : 1);
-#define WD_LAUNCH_PAIRS(MODE)                                                                            \
-    do {                                                                                                 \
-        if (ctx->nbr_t16)                                                                                \
-            hipLaunchKernelGGL((k_dense_pairs<MODE, true>), grid, dim3(kBlock), q_lds, ctx->stream, d);  \
-        else                                                                                             \
-            hipLaunchKernelGGL((k_dense_pairs<MODE, false>), grid, dim3(kBlock), q_lds, ctx->stream, d); \
+#define WD_LAUNCH_PAIRS(MODE)                                                                               \
+    do {                                                                                                    \
+        if (d.ginfo)                                                                                        \
+            hipLaunchKernelGGL((k_dense_pairs_win<MODE>), grid, dim3(kBlock), q_lds, ctx->stream, d);       \
+        if (ctx->n_window_groups < n_groups || !d.ginfo) {                                                  \
+            if (ctx->nbr_t16)                                                                               \
+                hipLaunchKernelGGL((k_dense_pairs<MODE, true>), grid, dim3(kBlock), q_lds, ctx->stream, d); \
+            else                                                                                            \
+                hipLaunchKernelGGL((k_dense_pairs<MODE, false>), grid, dim3(kBlock), q_lds, ctx->stream, d);\
+        }                                                                                                   \
     } while (0)
     if (pmode == 0)
         WD_LAUNCH_PAIRS(0);
@@ -607,6 +638,8 @@ int launch_dense(wd_ctx *ctx, const ScanArgs &a, dim3 grid, int n_tiles, int64_t
     else
         WD_LAUNCH_PAIRS(2);
 #undef WD_LAUNCH_PAIRS
+    const unsigned mark_blocks = (unsigned)((n_groups + kWave * kWaves - 1) / (kWave * kWaves));
+    hipLaunchKernelGGL(k_dense_mark, dim3(mark_blocks, (unsigned)n_tiles), dim3(kBlock), 0, ctx->stream, d);
     if (d.rows) {
         hipLaunchKernelGGL(k_dense_rank_words, dim3((unsigned)(d.mw_stride / kMarkBlock), (unsigned)n_tiles), dim3(kMarkBlock),
                            0, ctx->stream, d);
@@ -620,9 +653,7 @@ int launch_dense(wd_ctx *ctx, const ScanArgs &a, dim3 grid, int n_tiles, int64_t
         else
             hipLaunchKernelGGL((k_dense_pack<1, false>), grid1, dim3(kBlock), 0, ctx->stream, d);
     }
-    const unsigned bpt = (unsigned)((a.T + kBlock - 1) / kBlock);
-    const unsigned nvb = (bpt + kWaves - 1) / kWaves;
-    const dim3 vgrid(kXcds * ((nvb + kXcds - 1) / kXcds), (unsigned)n_tiles);
+    const dim3 vgrid(kXcds * ((mark_blocks + kXcds - 1) / kXcds), (unsigned)n_tiles);
     if (strided)
         hipLaunchKernelGGL((k_dense_verify<true>), vgrid, dim3(kBlock), 0, ctx->stream, d);
     else
@@ -733,8 +764,12 @@ void wd_destroy(wd_ctx *ctx)
     (void)hipFree(ctx->d_rel_t);
     (void)hipFree(ctx->d_udelta);
     (void)hipFree(ctx->d_guni);
+    (void)hipFree(ctx->d_ginfo);
     (void)hipFree(ctx->d_uoff);
     (void)hipFree(ctx->d_useg);
+    (void)hipFree(ctx->d_wdelta);
+    (void)hipFree(ctx->d_wlev);
+    (void)hipFree(ctx->d_wmask);
     (void)hipFree(ctx->d_tblflags);
     (void)hipFree(ctx->d_mark);
     (void)hipFree(ctx->d_sig);
@@ -824,6 +859,8 @@ int wd_set_option(wd_ctx *ctx, const char *name, int64_t value)
         ctx->fast_inflate = value ? 1 : 0;
     } else if (n == "dense_pack") {
         ctx->dense_pack = value < 0 ? -1 : (value ? 1 : 0);
+    } else if (n == "dense_windows") {
+        ctx->dense_windows = value ? 1 : 0;
     } else if (n == "dense_queue_cap") {
         if (value < 0)
             return WD_ERR_ARG;
@@ -855,6 +892,7 @@ int wd_get_option(wd_ctx *ctx, const char *name, int64_t *value)
     else if (n == "dense_tile_chunk") *value = ctx->dense_tile_chunk;
     else if (n == "dense_queue_cap") *value = ctx->dense_queue_cap;
     else if (n == "dense_pack") *value = ctx->dense_pack;
+    else if (n == "dense_windows") *value = ctx->dense_windows;
     else if (n == "fast_inflate") *value = ctx->fast_inflate;
     else if (n == "well_stride") *value = ctx->well_stride;
     else if (n == "null_stream") *value = ctx->stream == nullptr ? 1 : 0;
@@ -1132,7 +1170,7 @@ int wd_scan_async(wd_ctx *ctx, int n_tiles, int L, int mode, int k, const uint8_
     const int tile_chunk = std::max(1, std::min(ctx->dense_tile_chunk, n_tiles));
     // dense grid: 8 XCDs x (target blocks per XCD) x tile_chunk x (chunks of tiles), see k_dense_pairs
     const long long dense_bpt = (ctx->T + kBlock - 1) / kBlock;
-    const long long dense_blocks = (long long)kXcds * ((dense_bpt + kXcds - 1) / kXcds) * tile_chunk *
+    const long long dense_blocks = (long long)kXcds * ((dense_bpt + kXcds - 1) / kXcds) *
                                    ((n_tiles + tile_chunk - 1) / tile_chunk);
     const long long nblocks = lev_generic ? (long long)ctx->T * n_tiles
                               : use_dense ? dense_blocks
