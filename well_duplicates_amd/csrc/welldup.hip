@@ -141,6 +141,7 @@ struct wd_ctx {
     size_t mark_cap = 0;       // words
     int dense_pack = -1;                       // option: -1 = by survivor count, 0 = never, 1 = always
     int dense_windows = 1;                     // option: 0 = no LDS windows, every group gathers through L1
+    int dense_nt = 1;                          // option: the pack kernel streams the planes with non-temporal loads (0.97 -> 0.83 ms per 8 tiles)
     int fast_inflate = 1;                      // option: own gunzip first, zlib as referee (0 = zlib only)
     int well_stride = 1;                       // option: 1 = a plane per cycle, 4 = cycles interleaved by four
     int profile = 0;           // HIP events around every n-th scan (0 = off)
@@ -419,7 +420,8 @@ int ensure_dense_tables(wd_ctx *ctx)
         // groups of consecutive centres whose neighbours fall into a few runs of offsets: LDS
         // windows (k_dense_windows); the union of a group's offsets may be a little larger than
         // any one target's list
-        const int64_t kpad = std::min<int64_t>(kWinMaxK, (ctx->k_max + ctx->k_max / 2 + 8 + 31) & ~(int64_t)31);
+        // (a group that straddles the end of a grid row sees two patterns: up to twice the offsets)
+        const int64_t kpad = std::min<int64_t>(kWinMaxK, (2 * ctx->k_max + 8 + 31) & ~(int64_t)31);
         if (ctx->k_max >= 1 && ctx->k_max <= kpad) {
             ctx->win_kpad = (int)kpad;
             WD_HIP(ctx, hipMalloc((void **)&ctx->d_ginfo, (size_t)groups * sizeof(int32_t)));
@@ -560,7 +562,7 @@ int launch_dense(wd_ctx *ctx, const ScanArgs &a, dim3 grid, int n_tiles, int64_t
     const size_t mark_words = (size_t)n_tiles * d.mw_stride;
     const size_t part_need = (size_t)n_tiles * kDenseSlots * d.partial_stride;
     const size_t mask_need = (size_t)n_tiles * d.mask_stride;
-    if ((rc = dense_reserve(ctx, ctx->d_sig, ctx->sig_cap, (size_t)d.sig_stride * n_tiles * (lev2 ? 2 : 1), "signature planes")) ||
+    if ((rc = dense_reserve(ctx, ctx->d_sig, ctx->sig_cap, (size_t)d.sig_stride * n_tiles * ((lev2 || a.k > 0) ? 2 : 1), "signature planes")) ||
         (rc = dense_reserve(ctx, ctx->d_partial, ctx->partial_cap, part_need, "counter slots")) ||
         (rc = dense_reserve(ctx, ctx->d_mask, ctx->mask_cap, mask_need, "hit masks")) ||
         (rc = dense_reserve(ctx, ctx->d_queue, ctx->queue_cap, (size_t)(regions * q_per), "survivor queue")) ||
@@ -591,7 +593,8 @@ int launch_dense(wd_ctx *ctx, const ScanArgs &a, dim3 grid, int n_tiles, int64_t
     d.cand = ctx->d_cand;
     WD_HIP(ctx, hipMemsetAsync(ctx->d_cand, 0, (kDenseSlots + 1) * sizeof(uint32_t), ctx->stream));
     d.sig = ctx->d_sig;
-    d.sig2 = lev2 ? ctx->d_sig + (size_t)d.sig_stride * n_tiles : nullptr;     // Levenshtein: the screen words
+    // distances > 0: the compare stage reads 16-cycle screen words (k_dense_sig)
+    d.sig2 = (lev2 || a.k > 0) ? ctx->d_sig + (size_t)d.sig_stride * n_tiles : nullptr;
     d.partial = ctx->d_partial;
     d.mask = ctx->d_mask;
     d.queue = ctx->d_queue;
@@ -620,16 +623,16 @@ int launch_dense(wd_ctx *ctx, const ScanArgs &a, dim3 grid, int n_tiles, int64_t
                                             (unsigned)((n_tiles + tile_chunk - 1) / tile_chunk)),
                        dim3(kBlock), 0, ctx->stream, d);
     const int pmode = lev2 ? 2 : (a.k == 0 ? 0 : 1);
-#define WD_LAUNCH_PAIRS(MODE)                                                                               \
-    do {                                                                                                    \
-        if (d.ginfo)                                                                                        \
-            hipLaunchKernelGGL((k_dense_pairs_win<MODE>), grid, dim3(kBlock), q_lds, ctx->stream, d);       \
-        if (ctx->n_window_groups < n_groups || !d.ginfo) {                                                  \
-            if (ctx->nbr_t16)                                                                               \
-                hipLaunchKernelGGL((k_dense_pairs<MODE, true>), grid, dim3(kBlock), q_lds, ctx->stream, d); \
-            else                                                                                            \
-                hipLaunchKernelGGL((k_dense_pairs<MODE, false>), grid, dim3(kBlock), q_lds, ctx->stream, d);\
-        }                                                                                                   \
+#define WD_LAUNCH_PAIRS(MODE)                                                                                   \
+    do {                                                                                                        \
+        if (d.ginfo)                                                                                            \
+            hipLaunchKernelGGL((k_dense_pairs_win<MODE>), grid, dim3(kBlock), q_lds, ctx->stream, d);           \
+        if (ctx->n_window_groups < n_groups || !d.ginfo) {                                                      \
+            if (ctx->nbr_t16)                                                                                   \
+                hipLaunchKernelGGL((k_dense_pairs<MODE, true>), grid, dim3(kBlock), q_lds, ctx->stream, d);    \
+            else                                                                                                \
+                hipLaunchKernelGGL((k_dense_pairs<MODE, false>), grid, dim3(kBlock), q_lds, ctx->stream, d);  \
+        }                                                                                                       \
     } while (0)
     if (pmode == 0)
         WD_LAUNCH_PAIRS(0);
@@ -644,7 +647,9 @@ int launch_dense(wd_ctx *ctx, const ScanArgs &a, dim3 grid, int n_tiles, int64_t
         hipLaunchKernelGGL(k_dense_rank_words, dim3((unsigned)(d.mw_stride / kMarkBlock), (unsigned)n_tiles), dim3(kMarkBlock),
                            0, ctx->stream, d);
         hipLaunchKernelGGL(k_dense_rank_blocks, dim3((unsigned)n_tiles), dim3(1024), 0, ctx->stream, d);
-        if (aligned4 && strided)
+        if (aligned4 && strided && ctx->dense_nt)
+            hipLaunchKernelGGL((k_dense_pack<4, true, true>), grid4, dim3(kBlock), 0, ctx->stream, d);
+        else if (aligned4 && strided)
             hipLaunchKernelGGL((k_dense_pack<4, true>), grid4, dim3(kBlock), 0, ctx->stream, d);
         else if (aligned4)
             hipLaunchKernelGGL((k_dense_pack<4, false>), grid4, dim3(kBlock), 0, ctx->stream, d);
@@ -861,6 +866,8 @@ int wd_set_option(wd_ctx *ctx, const char *name, int64_t value)
         ctx->dense_pack = value < 0 ? -1 : (value ? 1 : 0);
     } else if (n == "dense_windows") {
         ctx->dense_windows = value ? 1 : 0;
+    } else if (n == "dense_nt") {
+        ctx->dense_nt = value ? 1 : 0;
     } else if (n == "dense_queue_cap") {
         if (value < 0)
             return WD_ERR_ARG;
@@ -893,6 +900,7 @@ int wd_get_option(wd_ctx *ctx, const char *name, int64_t *value)
     else if (n == "dense_queue_cap") *value = ctx->dense_queue_cap;
     else if (n == "dense_pack") *value = ctx->dense_pack;
     else if (n == "dense_windows") *value = ctx->dense_windows;
+    else if (n == "dense_nt") *value = ctx->dense_nt;
     else if (n == "fast_inflate") *value = ctx->fast_inflate;
     else if (n == "well_stride") *value = ctx->well_stride;
     else if (n == "null_stream") *value = ctx->stream == nullptr ? 1 : 0;
