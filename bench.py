@@ -1,11 +1,13 @@
 #!/usr/bin/env python3
 """bench.py - the headline benchmark: target x neighbour sequence compares per second.
 
-Workload (BASELINE.json configs[1], one per rank = weak scaling): one lane of a HiSeq-X style
-flowcell = 96 tiles x 2500 targets (prepare_cluster_indexes semantics, seed 13) x 5 levels,
-50 bp, HiSeq-4000 tile geometry (2743 x 1571 = 4 309 253 clusters/tile), synthetic BCL planes
-and filters generated on the device from the counter-based spec (well_duplicates_amd/synth.py:
-0.5 % no-calls, 70 % filter pass, 2 % planted near-duplicates).  Rank r scans lane r+1.
+Workload, one lane per rank (weak scaling), 2500 targets (prepare_cluster_indexes semantics, seed
+13) x 5 levels, 50 bp, HiSeq-4000 tile geometry (2743 x 1571 = 4 309 253 clusters/tile), synthetic
+BCL planes and filters generated on the device from the counter-based spec
+(well_duplicates_amd/synth.py: 0.5 % no-calls, 70 % filter pass, 2 % planted near-duplicates):
+  N = 1   BASELINE.json configs[1]: 1 lane x 96 tiles (--stype hiseq_x);
+  N > 1   BASELINE.json configs[2]: N lanes x 112 tiles (--stype hiseq_4000), tile-sharded.
+Rank r scans lane r+1.
 
 A "step" is one pass of the scan path over the rank's 96 resident tiles (all kernels of
 wd_scan_async) into that step's rows of the job's counter block.  For N > 1 the ranks' rows are
@@ -16,12 +18,21 @@ performed compare = one unit of the reference report's `Wells` column
 (count_well_duplicates.py:93), read back from the device's own counters.
 
 Extra objects on the JSON line:
-  roofline      HBM roofline of the dominant kernel (k_scan): algorithmic bytes
+  roofline      HBM roofline of the dominant kernel (k_scan_q): algorithmic bytes
                 B = C*(L+4) + Tv*(L+5) + 8*(1+5*levels)*tiles per launch over the
-                kernel's mean duration, measured with HIP events on the launch stream around
-                every 8th launch of the timed region itself.
+                kernel's mean duration, measured with HIP events on the launch stream around at
+                least 16 launches of the timed region itself; `traffic` = HBM bytes per launch from
+                the PMC counters of the same kernel on the same workload (profiles/traffic.json,
+                `traffic_source` says which run), `traffic_frac` = traffic / kernel time / peak.
   cpu_baseline  the C oracle (oracle/welldup_oracle.c, -O3, OpenMP over tiles) on a bounded
                 sample of the same tiles, on this box's host cores.
+  e2e           real files through the CLI path: a run directory of full-size tiles is written on
+                the fly (.bcl.gz, gzip -6, binned qualities), then count_well_duplicates runs on
+                it with the reference's default metric: seconds per tile, plane bytes per second.
+  other_modes   kernel times of the other compare modes / layouts / the dense all-centres path;
+                `alg_bytes_over_peak` is algorithmic bytes / time / 8 TB/s - it can exceed 1 where a
+                lazy kernel never fetches what the byte model charges - and `traffic_frac` is the
+                counter-based fraction beside it.
 """
 from __future__ import annotations
 
@@ -46,8 +57,9 @@ def parse():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--tiles", type=int, default=None,
                     help="tiles per rank (one lane); default: all tiles of --stype (96 / 112)")
-    ap.add_argument("--stype", default="hiseq_x", choices=["hiseq_x", "hiseq_4000"],
-                    help="lane layout: hiseq_x = 96 tiles (BASELINE configs[1]), hiseq_4000 = 112 (configs[2])")
+    ap.add_argument("--stype", default=None, choices=["hiseq_x", "hiseq_4000"],
+                    help="lane layout: hiseq_x = 96 tiles (BASELINE configs[1], default at N = 1), "
+                         "hiseq_4000 = 112 (configs[2], default at N > 1)")
     ap.add_argument("--targets", type=int, default=2500)
     ap.add_argument("--levels", type=int, default=5)
     ap.add_argument("--bases", type=int, default=50)
@@ -60,7 +72,12 @@ def parse():
     ap.add_argument("--profile-steps", type=int, default=20)
     ap.add_argument("--interleaved-tiles", type=int, default=96,
                     help="tiles of the interleaved-layout measurement under other_modes; 0 = skip")
-    ap.add_argument("--dense-tiles", type=int, default=4,
+    ap.add_argument("--e2e-tiles", type=int, default=4,
+                    help="full-size tiles of the end-to-end (real files) measurement; 0 = skip")
+    ap.add_argument("--novaseq-tiles", type=int, default=96,
+                    help="tiles of the BASELINE configs[3] shape (NovaSeq tiles, 10000 targets x 7 levels) reported "
+                         "under other_modes; 0 = skip")
+    ap.add_argument("--dense-tiles", type=int, default=8,
                     help="tiles of the all-centres probe (BASELINE configs[4] shape: every well a centre, "
                          "3 levels, 150 bp) reported under other_modes; 0 = skip")
     ap.add_argument("--option", action="append", default=[], help="name=value scanner option")
@@ -72,11 +89,36 @@ def parse():
     return ap.parse_args()
 
 
+def traffic_lookup(key, tiles):
+    """HBM bytes per scan of `tiles` tiles from the counter runs (profiles/traffic.json, made by
+    tools/make_traffic.py from the rocprofv3 --pmc passes) -> (bytes or None, source or reason)."""
+    tpath = os.path.join(REPO, "profiles", "traffic.json")
+    try:
+        entry = json.load(open(tpath)).get(key)
+    except Exception as e:                                    # noqa: BLE001
+        return None, "profiles/traffic.json unreadable: %s" % e
+    if not entry:
+        return None, "no counter run for %s in profiles/traffic.json" % key
+    src = "%s [%s]" % (entry["source"], key)
+    if entry["tiles_measured"] != tiles:
+        src += ", per-tile bytes of the %d-tile counter run x %d tiles" % (entry["tiles_measured"], tiles)
+    return int(entry["hbm_bytes_per_tile"] * tiles), src
+
+
+def with_traffic(res, key, tiles, ms):
+    """Add `traffic`, `traffic_frac`, `traffic_source` to a per-mode result dict."""
+    traffic, src = traffic_lookup(key, tiles)
+    res["traffic"] = traffic
+    res["traffic_frac"] = None if not (traffic and ms > 0) else round(traffic / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+    res["traffic_source"] = src
+    return res
+
+
 def dense_probe(device, n_tiles, rows, cols, levels=3, bases=150):
     """Kernel time of the dense path (scan_dense.inc) on n_tiles full-size tiles."""
     import numpy as np
     from well_duplicates_amd import synth
-    from well_duplicates_amd.scanner import Scanner, TileBatch, MODE_EQ, MODE_LEVENSHTEIN
+    from well_duplicates_amd.scanner import Scanner, TileBatch, MODE_EQ, MODE_HAMMING, MODE_LEVENSHTEIN
     n = rows * cols
     x, y = synth.honeycomb_pixels(rows, cols)
     sc = Scanner(device)
@@ -91,34 +133,155 @@ def dense_probe(device, n_tiles, rows, cols, levels=3, bases=150):
         out = sc.malloc(n_tiles * ncnt * 8)
         sc.scan_async(tb.tables, n_tiles, bases, n, MODE_EQ, 0, out)      # builds the tables
         sc.set_option("profile", 1)
-        # the reference's default metric first (Levenshtein <= 2), then equality for the counters
-        sc.scan_async(tb.tables, n_tiles, bases, n, MODE_LEVENSHTEIN, 2, out)
-        sc.profile_reset()
-        for _ in range(3):
-            sc.scan_async(tb.tables, n_tiles, bases, n, MODE_LEVENSHTEIN, 2, out)
-        lev_ms, lev_n = sc.profile_get()
-        lev_ms /= max(1, lev_n)
-        sc.profile_reset()
-        for _ in range(3):
-            sc.scan_async(tb.tables, n_tiles, bases, n, MODE_EQ, 0, out)
-        ms, launches = sc.profile_get()
-        ms /= max(1, launches)
-        blk = sc.d2h(out, n_tiles * ncnt * 8, np.int64).reshape(n_tiles, ncnt)
-        compares = int(blk[:, 1:1 + levels].sum())
         b_dense = n_tiles * (n * bases + 4 * n * (1 + P / T) + n)             # SURVEY.md 8d, dense form
         res = {"workload": "%d tiles x %d centres x %.1f neighbours, %d levels, %d bp, 2 %% planted"
                            % (n_tiles, T, P / T, levels, bases),
-               "kernel_ms": round(ms, 4), "ms_per_tile": round(ms / n_tiles, 4),
-               "compares_per_s": round(compares / (ms * 1e-3), 1),
-               "duplicates_found": int(blk[:, 1 + levels:1 + 2 * levels].sum()),
-               "algorithmic_bytes": int(b_dense), "frac_of_hbm_peak": round(b_dense / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-               "levenshtein_k2_kernel_ms": round(lev_ms, 4),
-               "levenshtein_k2_compares_per_s": round(compares / (lev_ms * 1e-3), 1),
-               "ring_generator_s": round(gen_s, 3)}
+               "algorithmic_bytes": int(b_dense), "ring_generator_s": round(gen_s, 3),
+               "window_groups": sc.get_option("dense_window_groups"), "groups": (T + 63) // 64}
+        # the reference's default metric (Levenshtein <= 2), Hamming <= 2, then equality for the counters
+        for name, mode, k, case in (("levenshtein_k2", MODE_LEVENSHTEIN, 2, "dense_lev2"),
+                                    ("hamming_k2", MODE_HAMMING, 2, "dense_ham2"), ("equality", MODE_EQ, 0, "dense_eq")):
+            sc.scan_async(tb.tables, n_tiles, bases, n, mode, k, out)
+            sc.profile_reset()
+            for _ in range(4):
+                sc.scan_async(tb.tables, n_tiles, bases, n, mode, k, out)
+            ms, launches = sc.profile_get()
+            ms /= max(1, launches)
+            blk = sc.d2h(out, n_tiles * ncnt * 8, np.int64).reshape(n_tiles, ncnt)
+            compares = int(blk[:, 1:1 + levels].sum())
+            res[name] = with_traffic(
+                {"kernel_ms": round(ms, 4), "ms_per_tile": round(ms / n_tiles, 4),
+                 "compares_per_s": round(compares / (ms * 1e-3), 1),
+                 "duplicates_found": int(blk[:, 1 + levels:1 + 2 * levels].sum()),
+                 "alg_bytes_over_peak": round(b_dense / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
+                "%s_T%d_l%d_L%d_plant%d" % (case, T, levels, bases, spec.plant_per_64k), n_tiles, ms)
         tb.free()
         return res
     finally:
         sc.close()
+
+
+def novaseq_probe(device, n_tiles, levels=7, targets=10000, bases=50):
+    """BASELINE configs[3] shape on one GPU: NovaSeq-style tiles (4 091 904 wells), 10 000 sampled
+    targets x 7 rings (device ring generator; the reference's own stops at 5), equality and the
+    reference's default Levenshtein <= 2.  (The .cbcl ingest of this config is exercised by
+    tests/test_gpu_novaseq.py; here the planes are resident.)"""
+    import numpy as np
+    from well_duplicates_amd import cluster_indexes, synth, workload
+    from well_duplicates_amd.scanner import Scanner, TileBatch, MODE_EQ, MODE_LEVENSHTEIN
+    rows, cols = workload.NOVASEQ_ROWS, workload.NOVASEQ_COLS
+    n = rows * cols
+    x, y = synth.honeycomb_pixels(rows, cols)
+    with Scanner(device) as sc:
+        t0 = time.perf_counter()
+        T, P = sc.targets_from_coords(x, y, cluster_indexes.sample_centres(n, targets, 13), levels=levels,
+                                      max_dists=cluster_indexes.max_dists_for(levels))
+        gen_s = time.perf_counter() - t0
+        spec = synth.SynthSpec(seed=4, n_clusters=n, row=cols)
+        tile_ids = workload.tiles_for_stype(workload.NOVASEQ_STYPE)[:n_tiles]
+        tb = TileBatch(sc, n_tiles, bases, n)
+        tb.fill_synthetic(spec, [(1, int(t)) for t in tile_ids], list(range(bases)))
+        ncnt = 1 + 5 * levels
+        out = sc.malloc(n_tiles * ncnt * 8)
+        sc.set_option("profile", 1)
+        res = {"workload": "%d of a lane's 936 tiles x %d wells, %d targets x %d rings (%.1f neighbours), %d bp"
+                           % (n_tiles, n, T, levels, P / T, bases), "ring_generator_s": round(gen_s, 3)}
+        for name, mode, k, case in (("equality", MODE_EQ, 0, "eq"), ("levenshtein_k2", MODE_LEVENSHTEIN, 2, "lev2")):
+            sc.scan_async(tb.tables, n_tiles, bases, n, mode, k, out)
+            sc.profile_reset()
+            for _ in range(5):
+                sc.scan_async(tb.tables, n_tiles, bases, n, mode, k, out)
+            ms, launches = sc.profile_get()
+            ms /= max(1, launches)
+            blk = sc.d2h(out, n_tiles * ncnt * 8, np.int64).reshape(n_tiles, ncnt)
+            C, Tv = int(blk[:, 1:1 + levels].sum()), int(blk[:, 0].sum())
+            b_alg = C * (bases + 4) + Tv * (bases + 5) + 8 * ncnt * n_tiles
+            res[name] = with_traffic(
+                {"kernel_ms": round(ms, 4), "compares": C, "compares_per_s": round(C / (ms * 1e-3), 1),
+                 "algorithmic_bytes": b_alg,
+                 "alg_bytes_over_peak": round(b_alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
+                "novaseq_%s_T%d_l%d_L%d" % (case, T, levels, bases), n_tiles, ms)
+        tb.free()
+        return res
+
+
+def e2e_probe(device, n_tiles, rows, cols, centre, lvl_off, nbr, cycles=50, threads=None):
+    """End to end on real files: a run directory of n_tiles full-size tiles (planes generated on the
+    GPU with binned qualities, gzip -6 .bcl.gz files written by a thread pool) and the targets file,
+    then this package's count_well_duplicates CLI with the reference's default metric (-e 2,
+    Levenshtein), -q -S: everything from process-level file reads to the printed report."""
+    import gzip
+    import io
+    import shutil
+    import tempfile
+    from concurrent.futures import ThreadPoolExecutor
+    from contextlib import redirect_stdout
+    from well_duplicates_amd import synth, workload
+    from well_duplicates_amd import count_well_duplicates as cwd
+    from well_duplicates_amd.scanner import Scanner, TileBatch
+    n = rows * cols
+    threads = threads or min(32, os.cpu_count() or 1)
+    spec = synth.SynthSpec(seed=2, n_clusters=n, row=cols, qual_levels=7)
+    tiles = [str(t) for t in workload.tiles_for_stype("hiseq_x")[:n_tiles]]
+    root = tempfile.mkdtemp(prefix="wd_e2e_")
+    try:
+        t0 = time.perf_counter()
+        ldir = os.path.join(root, "Data", "Intensities", "BaseCalls", "L001")
+        for c in range(cycles):
+            os.makedirs(os.path.join(ldir, "C%d.1" % (c + 1)))
+        with Scanner(device) as sc:
+            tb = TileBatch(sc, n_tiles, cycles, n)
+            tb.fill_synthetic(spec, [(1, int(t)) for t in tiles], list(range(cycles)))
+            gz_bytes = [0]
+
+            def write(job):
+                i, c = job
+                data = gzip.compress(synth.bcl_file_bytes(tb.download_plane(i, c)), compresslevel=6)
+                gz_bytes[0] += len(data)
+                with open(os.path.join(ldir, "C%d.1" % (c + 1), "s_1_%s.bcl.gz" % tiles[i]), "wb") as fh:
+                    fh.write(data)
+            with ThreadPoolExecutor(max_workers=threads) as pool:
+                list(pool.map(write, [(i, c) for i in range(n_tiles) for c in range(cycles)]))
+            for i, t in enumerate(tiles):
+                with open(os.path.join(ldir, "s_1_%s.filter" % t), "wb") as fh:
+                    fh.write(synth.filter_file_bytes(tb.download_filter(i)))
+            tb.free()
+        tfile = os.path.join(root, "targets.list")
+        with open(tfile, "w") as fh:
+            for t in range(centre.shape[0]):
+                fh.write("%d\n" % centre[t])
+                for l in range(lvl_off.shape[1] - 1):
+                    fh.write(",".join(str(int(w)) for w in nbr[lvl_off[t, l]:lvl_off[t, l + 1]]) + "\n")
+        write_s = time.perf_counter() - t0
+        levels = lvl_off.shape[1] - 1
+        argv = ["-f", tfile, "-n", str(centre.shape[0]), "-l", str(levels), "-s", "hiseq_x", "-r", root, "-i", "1",
+                "-t", ",".join(tiles), "--cycles", "0-%d" % cycles, "-q", "-S", "--threads", str(threads),
+                "--device", str(device), "--tile-batch", str(max(1, n_tiles // 2))]
+
+        def run(extra):
+            buf = io.StringIO()
+            t1 = time.perf_counter()
+            with redirect_stdout(buf):
+                cwd.main(argv + extra)
+            return time.perf_counter() - t1, buf.getvalue()
+        run([])                                               # page cache, allocator, first-use costs
+        best, text = min(run([]) for _ in range(2))
+        serial, text_s = min(run(["--serial-ingest"]) for _ in range(2))
+        plane_bytes = n_tiles * cycles * n
+        return {"what": "count_well_duplicates CLI (-e 2 Levenshtein, %d targets x %d levels, -q -S) on %d full-size "
+                        "tiles x %d cycles of .bcl.gz files (gzip -6, 7 quality bins), warm page cache; two batches "
+                        "of %d tiles" % (centre.shape[0], levels, n_tiles, cycles, max(1, n_tiles // 2)),
+                "tiles": n_tiles, "files": n_tiles * cycles, "gz_bytes": gz_bytes[0], "plane_bytes": plane_bytes,
+                "threads": threads, "seconds": round(best, 4), "s_per_tile": round(best / n_tiles, 4),
+                "plane_gb_per_s": round(plane_bytes / best / 1e9, 3),
+                "serial_ingest_seconds": round(serial, 4),
+                "overlap_gain": round(serial / best, 3) if best > 0 else None,
+                "same_report": text == text_s, "run_dir_write_s": round(write_s, 1),
+                "reference_s_per_tile": 7.9,
+                "reference_note": "unmodified reference, 1 core, same geometry, --hamming -e 0 (BASELINE.md; measured in "
+                                  "the build container, not on this box)"}
+    finally:
+        shutil.rmtree(root, ignore_errors=True)
 
 
 def main():
@@ -166,6 +329,8 @@ def main():
     centre, lvl_off, nbr = workload.honeycomb_targets(rows, cols, T, levels, seed=13)
     spec = synth.SynthSpec(seed=2, n_clusters=n_clusters, row=cols)
     lane = rank + 1
+    if args.stype is None:                                    # the layout BASELINE names for this N
+        args.stype = "hiseq_x" if world == 1 else "hiseq_4000"
     tile_ids = [int(t) for t in workload.tiles_for_stype(args.stype)]
     if args.tiles is None:
         args.tiles = len(tile_ids)
@@ -250,10 +415,10 @@ def main():
 
     run(args.warmup)
     sc.scan_status()
-    # HIP events around every 8th scan launch of the timed region, on the launch stream: the
-    # roofline's kernel time comes from launches that `value` is made of (every launch would cost
-    # the step 3-5 % in event records)
-    sc.set_option("profile", 8)
+    # HIP events around every n-th scan launch of the timed region, on the launch stream, at least
+    # 16 of them: the roofline's kernel time comes from launches that `value` is made of (every
+    # launch would cost the step 3-5 % in event records)
+    sc.set_option("profile", max(1, min(8, args.steps // 16)))
     sc.profile_reset()
     fence()
     t_start = time.perf_counter()
@@ -307,8 +472,12 @@ def main():
             for _ in range(5):
                 sc.scan_async(tb.tables, args.tiles, L, n_clusters, m2, k2, my_rows.data_ptr())
             o_ms, o_n = sc.profile_get()
-            other[name] = {"kernel_ms": round(o_ms / max(1, o_n), 5),
-                           "compares_per_s": round(compares_rank / (o_ms / max(1, o_n) * 1e-3), 1)}
+            o_ms /= max(1, o_n)
+            b_o = compares_rank * (L + 4) + valid_rank * (L + 5) + 8 * ncnt * args.tiles
+            other[name] = with_traffic(
+                {"kernel_ms": round(o_ms, 5), "compares_per_s": round(compares_rank / (o_ms * 1e-3), 1),
+                 "alg_bytes_over_peak": round(b_o / (o_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
+                "%s_T%d_l%d_L%d" % ({"hamming_k2": "ham2", "levenshtein_k2": "lev2"}[name], T, levels, L), args.tiles, o_ms)
         sc.scan_async(tb.tables, args.tiles, L, n_clusters, mode, k, my_rows.data_ptr())   # restore counters
         sc.scan_status()
         # the resident-layout option: the same tiles with their cycles interleaved by four
@@ -331,36 +500,35 @@ def main():
             i_ms /= max(1, i_n)
             c_il = int(mine[:n_il, 1:1 + levels].sum())
             b_il = c_il * (L + 4) + int(mine[:n_il, 0].sum()) * (L + 5) + 8 * ncnt * n_il
-            other["interleaved_by_4"] = {
-                "tiles": n_il, "kernel_ms": round(i_ms, 5), "compares_per_s": round(c_il / (i_ms * 1e-3), 1),
-                "frac_of_hbm_peak": round(b_il / (i_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                "same_counters_as_plane_layout": same}
+            other["interleaved_by_4"] = with_traffic(
+                {"tiles": n_il, "kernel_ms": round(i_ms, 5), "compares_per_s": round(c_il / (i_ms * 1e-3), 1),
+                 "alg_bytes_over_peak": round(b_il / (i_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                 "same_counters_as_plane_layout": same},
+                "il_T%d_l%d_L%d" % (T, levels, L), n_il, i_ms)
             il.free()
     sc.set_option("profile", 0)
     # BASELINE configs[4] in small: every well of a tile is a centre (device-generated rings,
     # 3 levels), 150 bp, 2 % planted duplicates as in SURVEY.md 8d; its own context and planes
     if rank == 0 and world == 1 and args.dense_tiles > 0 and args.profile_steps > 0 and args.mode == "eq":
         other["dense_all_centres"] = dense_probe(local_rank, args.dense_tiles, rows, cols)
+    if rank == 0 and world == 1 and args.novaseq_tiles > 0 and args.profile_steps > 0 and args.mode == "eq":
+        other["novaseq_cfg4"] = novaseq_probe(local_rank, args.novaseq_tiles)
     b_alg = compares_rank * (L + 4) + valid_rank * (L + 5) + 8 * ncnt * args.tiles
     achieved = b_alg / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0
-    traffic = None
-    tpath = os.path.join(REPO, "profiles", "traffic.json")
-    if os.path.exists(tpath):
-        try:
-            tj = json.load(open(tpath))
-            key = "%s_k%d_t%d_T%d_l%d_L%d_%s" % (args.mode, k, args.tiles, T, levels, L,
-                                                "full" if args.no_early_exit else "early")
-            traffic = tj.get(key, {}).get("hbm_bytes_per_launch")
-        except Exception:
-            traffic = None
+    case = {"eq": "eq", "hamming": "ham%d" % k, "levenshtein": "lev%d" % k}[args.mode]
+    if args.no_early_exit:
+        case = "full"
+    traffic, traffic_source = traffic_lookup("%s_T%d_l%d_L%d" % (case, T, levels, L), args.tiles)
     kernel_name = "k_scan_q" if (args.mode != "levenshtein" or k < 2) and not args.no_early_exit else "k_scan"
     roofline = {"bound": "hbm", "kernel": kernel_name, "achieved": round(achieved, 2),
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                "traffic": traffic, "algorithmic_bytes_per_launch": b_alg,
+                "traffic": traffic, "traffic_source": traffic_source,
+                "traffic_frac": None if not (traffic and kern_ms > 0) else round(traffic / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                "algorithmic_bytes_per_launch": b_alg,
                 "kernel_ms": round(kern_ms, 5), "launches_timed": launches,
                 "units_per_launch": compares_rank,
                 "full_gather_kernel_ms": None if worst is None else round(worst, 5),
-                "full_gather_frac": None if not worst else round(b_alg / (worst * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+                "full_gather_alg_bytes_over_peak": None if not worst else round(b_alg / (worst * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
 
     # ---- CPU baseline: the oracle on a bounded sample, rank 0 at N = 1 only --------------
     cpu = cpu_py = None
@@ -407,15 +575,23 @@ def main():
                   "sample": "first %d targets of 1 tile (%d compares) in %.2f s, pure-Python restatement of "
                             "get_seqs + the compare loop, planes already gunzipped" % (n_py, py_compares, t_py)}
 
+    e2e = None
+    if rank == 0 and world == 1 and args.e2e_tiles > 0 and args.profile_steps > 0 and args.mode == "eq":
+        tb.free()                                             # (the e2e run brings its own tiles)
+        tb = None
+        e2e = e2e_probe(local_rank, args.e2e_tiles, rows, cols, centre, lvl_off, nbr)
     if rank == 0:
+        per_lane = len(workload.tiles_for_stype(args.stype))
+        named = {("hiseq_x", 96): "BASELINE configs[1]", ("hiseq_4000", 112): "BASELINE configs[2] layout"}.get(
+            (args.stype, args.tiles), "custom layout")
         line = {
             "metric": "target x neighbour seq-compares/sec (whole node)",
             "value": round(value, 1), "unit": "compares/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 5), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-            "config": {"workload": "1 lane x %d tiles x %d targets x %d levels, %d bp per GPU "
-                                   "(BASELINE configs[1]; N GPUs = N lanes)" % (args.tiles, T, levels, L),
+            "config": {"workload": "%d lane(s) x %d tiles (%s) x %d targets x %d levels, %d bp; one lane per GPU (%s)"
+                                   % (world, args.tiles, args.stype, T, levels, L, named),
                        "mode": args.mode, "k": k, "early_exit": not args.no_early_exit,
                        "clusters_per_tile": n_clusters, "compares_per_step": compares_all,
                        "valid_targets_per_rank": valid_rank, "parallelism": "tiles sharded, %d rank(s)" % world,
@@ -424,10 +600,12 @@ def main():
             "roofline": roofline,
             "cpu_baseline": cpu,
             "cpu_baseline_python": cpu_py,
+            "e2e": e2e,
             "other_modes": other,
         }
         print(json.dumps(line))
-    tb.free()
+    if tb is not None:
+        tb.free()
     sc.close()
     if use_dist:
         dist.destroy_process_group()

@@ -20,7 +20,9 @@
  *       WD_ERR_EMPTY_LEVEL  -> AssertionError   (count_well_duplicates.py:249)
  *       WD_ERR_ARG          -> ValueError
  *       WD_ERR_NO_WELLS     -> RuntimeError     (prepare_cluster_indexes.py:70-76)
- *       WD_ERR_IO           -> FileNotFoundError / OSError (bcl_direct_reader.py:207-216)
+ *       WD_ERR_IO           -> FileNotFoundError (bcl_direct_reader.py:207-216: the file cannot be opened)
+ *       WD_ERR_CORRUPT      -> gzip.BadGzipFile / zlib.error (:208-209: what gzip.open().read() raises on bad data)
+ *       WD_ERR_TRUNCATED    -> EOFError         (:208-209: ... on a file that ends early)
  *       WD_ERR_FORMAT       -> AssertionError   (bcl_direct_reader.py:151, :236, :338)
  *       everything else     -> RuntimeError
  */
@@ -46,6 +48,8 @@ extern "C" {
 #define WD_ERR_NO_WELLS (-9)
 #define WD_ERR_IO (-10)
 #define WD_ERR_FORMAT (-11)
+#define WD_ERR_CORRUPT (-12)
+#define WD_ERR_TRUNCATED (-13)
 
 /* Compare modes.  The reference counts a duplicate when dist <= edit_distance
  * (count_well_duplicates.py:258) with dist = Levenshtein.distance, or Levenshtein.hamming
@@ -211,7 +215,8 @@ int wd_interleave4(wd_ctx *ctx, const uint8_t *const src[4], int64_t n_clusters,
  * All members of a gzip file src[0, src_len) -> dst (at most dst_cap bytes), *produced = bytes
  * written.  mode 0: zlib.  mode 1: the library's own RFC 1951/1952 decoder (CRC-32 and length of
  * every member checked); it declines - WD_ERR_UNSUPPORTED - whatever it does not like, and the
- * loaders then decode the file with zlib.  WD_ERR_IO: corrupt, truncated or longer than dst_cap. */
+ * loaders then decode the file with zlib.  WD_ERR_CORRUPT / WD_ERR_TRUNCATED: bad or short
+ * stream; WD_ERR_IO: more data than dst_cap. */
 int wd_gunzip(const uint8_t *src, size_t src_len, uint8_t *dst, size_t dst_cap, size_t *produced, int mode);
 
 /* NovaSeq: one tile's block of a `L00<lane>_<surface>.cbcl` file -> an n_clusters-byte plane on

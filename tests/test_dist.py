@@ -55,7 +55,12 @@ def _worker(rank, world, port, name, run_idx, out_dir):
     r, w, _ = wdist.env_rank()
     mine = wdist.shard(items, r, w)
     rows = _device_style_rows(name, run, mine)
-    full = wdist.merge_blocks(rows, len(items), r, w).numpy()
+    assert not wdist.any_rank_failed(False, w)
+    assert wdist.any_rank_failed(rank == world - 1, w)         # one rank's failure is everybody's
+    full = wdist.merge_blocks(rows, len(items), r, w, backend="gloo")
+    assert isinstance(full, np.ndarray)
+    logs = wdist.gather_dicts({item: ["line of rank %d" % rank] for item in mine}, w)
+    assert sorted(logs) == sorted(items) and logs[items[0]] == ["line of rank 0"]
     slowest = wdist.max_over_ranks(float(rank + 1), w)
     assert slowest == float(world)
     np.save(os.path.join(out_dir, "full_%d.npy" % rank), full)

@@ -68,33 +68,106 @@ def test_cli_tile_batching_and_errors(tmp_path_factory):
                   "-t", "1103", "-i", "1", "-q", "--cycles", "0-50", "-l", "5"])
 
 
-def test_cli_two_ranks_one_gpu(tmp_path_factory, tmp_path):
-    """torchrun with 2 ranks (both on GPU 0, gloo for the collective): tiles are sharded, the
-    merged report and duplicate log equal the reference's single-process output."""
+def _torchrun(argv, nproc):
+    import socket
     import subprocess
     import sys
-    fx, run_dir = _run_dir(tmp_path_factory, "far")
-    run = fx["runs"][2]                                   # Levenshtein <= 2, 3 tiles
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    return subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc),
+                           "--master-addr", "127.0.0.1", "--master-port", str(port),
+                           "-m", "well_duplicates_amd.count_well_duplicates"] + argv,
+                          cwd=repo, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+
+
+@pytest.mark.parametrize("name,run_idx,nproc", [("mid", 2, 2), ("mid", 0, 3), ("far", 2, 2)])
+def test_cli_ranks_share_one_gpu(tmp_path_factory, tmp_path, name, run_idx, nproc):
+    """torchrun with 2 and 3 ranks (all on GPU 0, gloo for the collective): the flat (lane, tile)
+    list - 2 lanes x 2 tiles for `mid`, so ranks own parts of different lanes - is sharded, ONE
+    all-reduce merges the rows, and rank 0 prints the lanes in order: report and duplicate log
+    equal the reference's single-process output."""
+    fx, run_dir = _run_dir(tmp_path_factory, name)
+    run = fx["runs"][run_idx]
     argv = ["-f", os.path.join(GOLD, fx["targets_file"]), "-n", str(fx["n_targets"]),
             "-l", str(fx["levels"]), "-s", fx.get("stype", "hiseq_4000"), "-r", run_dir,
             "-t", ",".join(fx["tiles"]), "-i", ",".join(str(l) for l in fx["lanes"])]
     report_file = str(tmp_path / "report.txt")
     argv += run["flags"] + ["--device", "0", "--dist-backend", "gloo", "-o", report_file]
-    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    import socket
-    with socket.socket() as sk:
-        sk.bind(("127.0.0.1", 0))
-        port = sk.getsockname()[1]
-    res = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
-                          "--master-addr", "127.0.0.1", "--master-port", str(port),
-                          "-m", "well_duplicates_amd.count_well_duplicates"] + argv,
-                         cwd=repo, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    res = _torchrun(argv, nproc)
     assert res.returncode == 0, res.stderr.decode()[-2000:]
     # (gloo prints connection banners on stdout, hence the report goes to a file here)
     assert open(report_file).read() == run["stdout"]
     keep = ("center seq at", "well seq at", "edit distance:")
     log = [ln for ln in res.stderr.decode().splitlines() if ln.startswith(keep)]
     assert log == run["dup_log"]
+
+
+def test_cli_failing_rank_takes_the_others_down(tmp_path_factory, tmp_path):
+    """One rank's input is broken (a cycle file of ITS tile is missing): every rank leaves with
+    an error instead of waiting in the collective, and the report is not written."""
+    fx, run_dir = _run_dir(tmp_path_factory, "mid")
+    run = fx["runs"][0]
+    victim = os.path.join(run_dir, "Data", "Intensities", "BaseCalls", "L002", "C7.1")
+    gone = [f for f in os.listdir(victim) if "1102" in f]
+    assert gone
+    for f in gone:
+        os.remove(os.path.join(victim, f))
+    argv = ["-f", os.path.join(GOLD, fx["targets_file"]), "-n", str(fx["n_targets"]),
+            "-l", str(fx["levels"]), "-s", fx.get("stype", "hiseq_4000"), "-r", run_dir,
+            "-t", ",".join(fx["tiles"]), "-i", ",".join(str(l) for l in fx["lanes"])]
+    report_file = str(tmp_path / "report.txt")
+    argv += run["flags"] + ["--device", "0", "--dist-backend", "gloo", "-o", report_file, "-q"]
+    res = _torchrun(argv, 2)
+    assert res.returncode != 0
+    err = res.stderr.decode()
+    assert "FileNotFoundError" in err and "another rank failed" in err
+    assert not os.path.exists(report_file) or open(report_file).read() == ""
+
+
+def test_cli_missing_cycle_file_is_a_clean_error(tmp_path_factory):
+    """A run folder that lacks one cycle's file of one tile: FileNotFoundError as in the reference
+    (bcl_direct_reader.py:207-216) - raised only after every loader thread has finished, so
+    nothing writes into freed buffers - and the process can go on using the GPU."""
+    fx, run_dir = _run_dir(tmp_path_factory, "dead_tile")
+    run = fx["runs"][0]
+    victim = os.path.join(run_dir, "Data", "Intensities", "BaseCalls", "L001", "C3.1")
+    for f in [f for f in os.listdir(victim) if "1102" in f]:
+        os.remove(os.path.join(victim, f))
+    with pytest.raises(FileNotFoundError):
+        _cli(fx, run_dir, run, ["--threads", "8", "--tile-batch", "1"])
+    with pytest.raises(FileNotFoundError):
+        _cli(fx, run_dir, run, ["--threads", "8"])
+    fx2, run_dir2 = _run_dir(tmp_path_factory, "mid_subset")      # the GPU is still fine
+    out, _ = _cli(fx2, run_dir2, fx2["runs"][0])
+    assert out == fx2["runs"][0]["stdout"]
+
+
+def test_cli_collective_through_the_library(tmp_path_factory):
+    """--dist-backend wd: the counter block is summed by wd_allreduce_counts, the library's own
+    RCCL binding (communicator of this one rank; the unique id travels through the process
+    group, here a single-process gloo group)."""
+    import torch.distributed as tdist
+    fx, run_dir = _run_dir(tmp_path_factory, "mid")
+    run = fx["runs"][2]
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    from well_duplicates_amd import dist as wdist
+    from well_duplicates_amd.scanner import Scanner
+    import numpy as np
+    tdist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1)
+    try:
+        with Scanner(0) as sc:
+            rows = np.arange(4 * 16, dtype=np.int64).reshape(4, 16) * 1234567
+            full = wdist.merge_blocks(rows, 4, 0, 1, backend="wd", scanner=sc)
+            assert (full == rows).all()
+    finally:
+        tdist.destroy_process_group()
+    out, _ = _cli(fx, run_dir, run)
+    assert out == run["stdout"]
 
 
 def test_cli_all_wells_equals_targets_file_with_every_well(tmp_path):

@@ -77,11 +77,28 @@ def test_errors_and_odd_files(sc, run_dir, tmp_path):
     q.write_bytes(gzip.compress(raw[:-10]))
     with pytest.raises(IndexError):
         sc.load_bcl_gz(str(q), dst, n)
-    # not gzip at all
+    # what gzip.open(..).read() raises in the reference (bcl_direct_reader.py:208-209), with the file named:
+    # not gzip at all -> BadGzipFile
     r = tmp_path / "junk.bcl.gz"
     r.write_bytes(b"hello world" * 10)
-    with pytest.raises(FileNotFoundError):
+    with pytest.raises(gzip.BadGzipFile, match="junk.bcl.gz"):
         sc.load_bcl_gz(str(r), dst, n)
+    # the compressed stream ends early -> EOFError
+    whole = gzip.compress(raw)
+    t = tmp_path / "cut.bcl.gz"
+    t.write_bytes(whole[:len(whole) // 2])
+    with pytest.raises(EOFError, match="cut.bcl.gz"):
+        sc.load_bcl_gz(str(t), dst, n)
+    # bad data inside the stream -> zlib.error
+    import zlib
+    dmg = bytearray(whole)
+    for pos in range(len(dmg) // 2, len(dmg) // 2 + 64):
+        dmg[pos] ^= 0xFF
+    u = tmp_path / "damaged.bcl.gz"
+    u.write_bytes(bytes(dmg))
+    with pytest.raises((zlib.error, gzip.BadGzipFile), match="damaged.bcl.gz"):
+        sc.load_bcl_gz(str(u), dst, n)
+    assert not issubclass(zlib.error, FileNotFoundError)     # (the CLI only falls back to .cbcl when the file is absent)
     # bad filter header version
     f = tmp_path / "s_1_9.filter"
     f.write_bytes(struct.pack("<III", 0, 2, 5) + b"\1" * 5)

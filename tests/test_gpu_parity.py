@@ -597,6 +597,78 @@ def test_less_travelled_paths(sc):
         tb.free()
 
 
+def test_known_answer_pairs_through_the_device(sc):
+    """tests/test_oracle_golden.py's hand-checked DNA pairs (the definitions python-Levenshtein
+    publishes, pinned there by the package's own doc examples), each as a two-well tile: well 0 is
+    the centre, well 1 its only neighbour.  For every threshold the device counts the pair exactly
+    when the tabulated distance is within it, and the hit log carries the tabulated distance."""
+    from test_oracle_golden import DNA_KNOWN_ANSWERS
+    code = {"N": 0, "A": 4 | 0, "C": 4 | 1, "G": 4 | 2, "T": 4 | 3}     # BCL byte: quality bits | base, 0 = no-call
+    L = len(DNA_KNOWN_ANSWERS[0][0])
+    n_pairs = len(DNA_KNOWN_ANSWERS)
+    # one tile holds all pairs: wells 2i (centre) and 2i + 1 (neighbour)
+    n = 2 * n_pairs
+    planes = np.zeros((L, n), dtype=np.uint8)
+    for i, (a, b, _, _) in enumerate(DNA_KNOWN_ANSWERS):
+        for c in range(L):
+            planes[c, 2 * i] = code[a[c]]
+            planes[c, 2 * i + 1] = code[b[c]]
+    centre = np.arange(0, n, 2, dtype=np.int32)
+    lvl_off = np.stack([np.arange(n_pairs), np.arange(n_pairs) + 1], axis=1).astype(np.int32)
+    nbr = np.arange(1, n, 2, dtype=np.int32)
+    sc.set_targets(centre, lvl_off, nbr)
+    tb = TileBatch(sc, 1, L, n)
+    try:
+        tb.upload_tile(0, planes, np.ones(n, dtype=np.uint8))
+        for mode, col in ((2, 2), (1, 3)):
+            for k in range(0, L + 2):
+                sc.hitlog_enable(64)
+                bl, pt = tb.count(mode, k, per_target=True)
+                hits, total = sc.hitlog_fetch(64)
+                sc.hitlog_enable(0)
+                want = [1 if row[col] <= k else 0 for row in DNA_KNOWN_ANSWERS]
+                assert pt[0, :, 0].tolist() == want, (mode, k)
+                assert bl[0, 2] == sum(want) == total
+                got = {int(h["target"]): int(h["dist"]) for h in hits}
+                assert got == {i: row[col] for i, row in enumerate(DNA_KNOWN_ANSWERS) if row[col] <= k}, (mode, k)
+        bl, pt = tb.count(0, 0, per_target=True)     # equality = distance 0 under either metric
+        assert pt[0, :, 0].tolist() == [1 if row[2] == 0 else 0 for row in DNA_KNOWN_ANSWERS]
+    finally:
+        tb.free()
+
+
+@pytest.mark.parametrize("L,k", [(12, 12), (12, 40), (30, 30)])
+def test_hit_log_holds_edit_distance_when_threshold_reaches_read_length(sc, L, k):
+    """Levenshtein with -e >= read length: every pair counts (the tallies are a Hamming problem),
+    but the reference logs each pair's true edit distance (count_well_duplicates.py:252, :262),
+    which can be smaller than the number of mismatching positions."""
+    rng = np.random.default_rng(L + k)
+    spec = synth.SynthSpec(seed=90 + L, n_clusters=4001, row=61, plant_per_64k=20000, nocall_per_64k=3000)
+    T, levels = 120, 3
+    centre, lvl_off, nbr = _random_case(rng, spec.n_clusters, T, levels, ring=7)
+    sc.set_targets(centre, lvl_off, nbr)
+    tb = TileBatch(sc, 1, L, spec.n_clusters)
+    tb.fill_synthetic(spec, [(1, 1101)], list(range(L)))
+    planes, filt, c2, n2, _ = compact_tile(spec, 1, 1101, list(range(L)), centre, nbr)
+    try:
+        want_bl, want_pt = tb.count(2, k, per_target=True)            # no hit log: the Hamming rewrite
+        sc.hitlog_enable(100000)
+        bl, pt = tb.count(2, k, per_target=True)
+        hits, total = sc.hitlog_fetch(100000)
+        sc.hitlog_enable(0)
+        assert (bl == want_bl).all() and (pt == want_pt).all()
+        valid, dups, lens, dist = oracle.count_tile(planes, filt, c2, lvl_off, n2, 2, k, want_dist=True)
+        assert (blocks_to_reference(bl[0], levels) == oracle.tally_tile(valid, dups, lens)).all()
+        want = sorted((t, p, int(dist[p])) for t in range(T) if valid[t]
+                      for p in range(lvl_off[t, 0], lvl_off[t, levels]))
+        assert total == len(want) == int(dups[valid == 1].sum())
+        assert sorted((int(h["target"]), int(h["slot"]), int(h["dist"])) for h in hits) == want
+        ham = oracle.count_tile(planes, filt, c2, lvl_off, n2, 1, k, want_dist=True)[3]
+        assert (dist[[p for _, p, _ in want]] < ham[[p for _, p, _ in want]]).any()      # the case matters
+    finally:
+        tb.free()
+
+
 @pytest.mark.parametrize("L", [1, 3, 4, 5, 8, 23, 50])
 def test_interleaved_layout_equals_plane_layout(sc, L):
     """The resident layout option (cycles interleaved by four, include/welldup.h wd_interleave4):

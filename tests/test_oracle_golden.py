@@ -97,6 +97,37 @@ def test_distance_functions():
         oracle.hamming("AC", "A")
 
 
+# Known answers for the third-party metric (count_well_duplicates.py:9, :200, :252).  The reference
+# pins nothing here; these are the examples the python-Levenshtein package publishes in the
+# docstrings of `distance` and `hamming` (7 and 5 for both functions), plus the editops example's
+# pair ('spam' -> 'park' takes three operations).
+LEVENSHTEIN_DOC_EXAMPLES = [("Hello world!", "Holly grail!", 7, 7), ("Brian", "Jesus", 5, 5), ("spam", "park", 3, 4)]
+# Pairs over the reads' own alphabet with answers worked out by hand from the two definitions:
+# (a, b, edit distance, Hamming distance) - the GPU test sends the same table through the HIP path.
+DNA_KNOWN_ANSWERS = [
+    ("ACGTACGTAC", "ACGTACGTAC", 0, 0),
+    ("ACGTACGTAC", "ACGTTCGTAC", 1, 1),            # one substitution
+    ("ACGTACGTAC", "CGTACGTACA", 2, 10),           # shifted by one: delete the first base, append one
+    ("ACGTACGTAC", "AACGTACGTA", 2, 9),            # shifted the other way: only the first base agrees in place
+    ("ACGTNACGTN", "ACGTAACGTN", 1, 1),            # a no-call is a symbol of its own: N vs A mismatches
+    ("NNNNNNNNNN", "NNNNNNNNNN", 0, 0),            # ... and N matches N (bcl_direct_reader.py:181)
+    ("AAAAACCCCC", "CCCCCAAAAA", 10, 10),
+    ("ACACACACAC", "CACACACACA", 2, 10),
+    ("ACGTACGTAC", "ACGTCAGTAC", 2, 2),            # a transposition costs two
+    ("AGGTCACTGA", "AGTCACTGAA", 2, 7),            # delete the third base, append one: AG.. and ..A agree in place
+]
+
+
+def test_published_and_hand_checked_distances():
+    for a, b, lev, ham in LEVENSHTEIN_DOC_EXAMPLES:
+        assert oracle.py_levenshtein(a, b) == lev
+        if len(a) == len(b):
+            assert oracle.py_hamming(a, b) == ham
+    for a, b, lev, ham in DNA_KNOWN_ANSWERS:
+        assert oracle.py_levenshtein(a, b) == lev == oracle.levenshtein(a, b), (a, b)
+        assert oracle.py_hamming(a, b) == ham == oracle.hamming(a, b), (a, b)
+
+
 def test_oracle_errors():
     planes = [np.array([1, 2, 3, 4], dtype=np.uint8)]
     filt = np.ones(4, dtype=np.uint8)

@@ -32,7 +32,7 @@ DENSE = {"dense_eq": (0, 0), "dense_ham2": (1, 2), "dense_lev2": (2, 2)}
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--case", required=True)
-    ap.add_argument("--workload", default="sparse", choices=["sparse", "cfg4"])
+    ap.add_argument("--workload", default="sparse", choices=["sparse", "cfg4", "novaseq"])
     ap.add_argument("--tiles", type=int, default=None)
     ap.add_argument("--reps", type=int, default=6)
     ap.add_argument("--plant", type=int, default=1311, help="planted wells per 65536 (1311 = 2 %%)")
@@ -53,10 +53,19 @@ def main():
         mode, k = SPARSE[a.case]
         T, levels, L = (2500, 5, 50) if a.workload == "sparse" else (10000, 7, 50)
         tiles = a.tiles or 96
-        centre, lvl_off, nbr = workload.honeycomb_targets(rows, cols, T, levels, 13)
-        sc.set_targets(centre, lvl_off, nbr)
-        P = int(nbr.shape[0])
-        spec = synth.SynthSpec(seed=2, n_clusters=n, row=cols)
+        if a.workload == "novaseq":                    # BASELINE configs[3]: NovaSeq tiles, device-generated rings
+            from well_duplicates_amd import cluster_indexes
+            rows, cols = workload.NOVASEQ_ROWS, workload.NOVASEQ_COLS
+            n = rows * cols
+            x, y = synth.honeycomb_pixels(rows, cols)
+            T, P = sc.targets_from_coords(x, y, cluster_indexes.sample_centres(n, T, 13), levels=levels,
+                                          max_dists=cluster_indexes.max_dists_for(levels))
+            spec = synth.SynthSpec(seed=4, n_clusters=n, row=cols)
+        else:
+            centre, lvl_off, nbr = workload.honeycomb_targets(rows, cols, T, levels, 13)
+            sc.set_targets(centre, lvl_off, nbr)
+            P = int(nbr.shape[0])
+            spec = synth.SynthSpec(seed=2, n_clusters=n, row=cols)
         interleave = 4 if a.case == "il" else 1
     for opt in a.option:
         name, val = opt.split("=")
@@ -89,7 +98,8 @@ def main():
         extra = {"groups": (T + 63) // 64, "uniform_groups": sc.get_option("dense_uniform_groups"),
                  "window_groups": sc.get_option("dense_window_groups"),
                  "window_dwords": sc.get_option("dense_window_dwords")}
-    print(json.dumps({**extra, "case": a.case, "workload": "dense" if a.case in DENSE else a.workload, "tiles": tiles,
+    case_name = ("novaseq_" + a.case) if a.workload == "novaseq" else a.case
+    print(json.dumps({**extra, "case": case_name, "workload": "dense" if a.case in DENSE else a.workload, "tiles": tiles,
                       "T": T, "levels": levels, "L": L, "mode": mode, "k": k, "plant_per_64k": spec.plant_per_64k,
                       "scans_timed": cnt, "kernel_ms": round(ms, 5), "compares": C, "valid_targets": Tv,
                       "duplicates": int(blk[:, 1 + levels:1 + 2 * levels].sum()),

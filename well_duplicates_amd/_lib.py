@@ -19,7 +19,7 @@ LIB_PATH = os.environ.get("WELLDUP_LIB") or os.path.join(HERE, "libwelldup.so")
 
 OK = 0
 ERR_ARG, ERR_INDEX, ERR_EMPTY_LEVEL, ERR_HIP, ERR_NOMEM, ERR_STATE, ERR_UNSUPPORTED, ERR_COMM, \
-    ERR_NO_WELLS, ERR_IO, ERR_FORMAT = -1, -2, -3, -4, -5, -6, -7, -8, -9, -10, -11
+    ERR_NO_WELLS, ERR_IO, ERR_FORMAT, ERR_CORRUPT, ERR_TRUNCATED = -1, -2, -3, -4, -5, -6, -7, -8, -9, -10, -11, -12, -13
 MODE_EQ, MODE_HAMMING, MODE_LEVENSHTEIN = 0, 1, 2
 MAX_LEVELS = 32
 INVALID_TARGET = 0xFFFFFFFF

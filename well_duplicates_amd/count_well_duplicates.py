@@ -10,17 +10,18 @@ Flow per lane (the reference's unit of output, :207-269):
 Unless -q is given the stderr log is reproduced too, including the three lines the
 reference prints per duplicate (:258-262), from the device's hit list.
 
-Multi-GPU: started under torchrun (one process per GPU) the tiles of every lane are
-block-partitioned over the ranks, each rank scans its share on its own GPU, one int64
-all-reduce merges the per-tile counter rows (well_duplicates_amd/dist.py) and rank 0 prints
-the report - identical to the single-GPU output.
+Multi-GPU: started under torchrun (one process per GPU) the flat list of (lane, tile) items is
+block-partitioned over the ranks, each rank scans its share on its own GPU, ONE int64
+all-reduce per run merges the per-tile counter rows (well_duplicates_amd/dist.py) and rank 0
+prints the lanes in order - identical to the single-GPU output.
 
 Differences from the reference, all deliberate:
   * a lane with valid targets but no duplicate prints 0.00 % instead of dying with
     ZeroDivisionError (F5); --strict restores the exception;
   * `-t` with a pattern that matches nothing raises the AssertionError the reference
     intends (its own message formatting raises NameError first);
-  * extra flags: --device, --dist-backend, --tile-batch, --threads, --strict, -o/--output.
+  * extra flags: --device, --dist-backend, --tile-batch, --threads, --strict, -o/--output,
+    --all-wells, --slocs, --serial-ingest.
 """
 from __future__ import annotations
 
@@ -84,8 +85,10 @@ def parse_args(argv=None):
     p.add_argument("--version", action="version", version=str(__VERSION__))
     p.add_argument("--device", type=int, default=None,
                    help="GPU to run on (default: LOCAL_RANK under torchrun, else 0)")
-    p.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
-                   help="collective backend under torchrun (nccl = RCCL; gloo = CPU, for rehearsals)")
+    p.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo", "wd"],
+                   help="the one collective under torchrun: nccl = RCCL through torch.distributed; "
+                        "wd = RCCL through libwelldup's own binding (wd_allreduce_counts; torch only carries "
+                        "the unique id); gloo = CPU, for rehearsals")
     p.add_argument("--tile-batch", type=int, default=32,
                    help="tiles kept resident in HBM and scanned per launch")
     p.add_argument("--threads", type=int, default=min(32, os.cpu_count() or 1),
@@ -98,6 +101,9 @@ def parse_args(argv=None):
                         "prepare_cluster_indexes.py; the per-duplicate log is not written in this mode")
     p.add_argument("--slocs", default=None,
                    help="s.locs file for --all-wells (default: <run>/Data/Intensities/s.locs)")
+    p.add_argument("--serial-ingest", action="store_true",
+                   help="load a batch of tiles only after the previous one has been scanned (for measuring "
+                        "what the double-buffered ingest gains)")
     p.add_argument("--strict", action="store_true",
                    help="reproduce the reference's ZeroDivisionError on a lane without duplicates")
     args = p.parse_args(argv)
@@ -112,46 +118,79 @@ def _decode(seq_bytes: np.ndarray) -> str:
     return lut[np.where(seq_bytes == 0, 0, (seq_bytes & 3) + 1)].tobytes().decode()
 
 
+class _Loading:
+    """One batch of tiles on its way into HBM: the TileBatch and the loader pool's futures."""
+
+    def __init__(self, chunk, handles, tb, futures):
+        self.chunk, self.handles, self.tb, self.futures = chunk, handles, tb, futures
+
+    def wait(self):
+        for f in self.futures:
+            f.result()                      # re-raises the loader's exception (FileNotFoundError, ...)
+
+
 def scan_lane(sc: Scanner, reader, lane, tiles, cycle_list, mode, k, csr, wells, tile_batch,
-              threads, want_log):
-    """All tiles of one lane -> ({tile: TileCounts}, {tile: [log lines]})."""
+              threads, want_log, overlap=True):
+    """The given tiles of one lane -> ({tile: TileCounts}, {tile: [log lines]}).
+
+    Double-buffered: while the GPU scans batch n (and its report rows and log lines are put
+    together), the loader threads are already gunzipping and copying batch n + 1 into a second
+    TileBatch (the ctypes calls release the GIL).  Whatever goes wrong, every loader thread has
+    finished before a TileBatch is freed or the exception leaves this function: the threads
+    write through the scanner's copy streams into the batches' planes.
+    """
     centre, lvl_off, nbr = csr
     levels = lvl_off.shape[1] - 1
     counts, logs = {}, {}
+    batches = [tiles[b0:b0 + tile_batch] for b0 in range(0, len(tiles), tile_batch)]
     pool = ThreadPoolExecutor(max_workers=max(1, threads))
-    for b0 in range(0, len(tiles), tile_batch):
-        chunk = tiles[b0:b0 + tile_batch]
+    live = []                               # TileBatches not yet freed
+
+    def start(chunk):
+        """Submit every load of a batch; returns at once."""
         handles = [reader.get_tile(lane, t) for t in chunk]
-        n_clusters = handles[0].num_clusters if handles else 0
+        n_clusters = handles[0].num_clusters
         for h in handles:
             # one targets file, hence one geometry, per flowcell (README.md:14)
             if h.num_clusters != n_clusters:
                 raise RuntimeError("tiles of one batch differ in cluster count")
+        if wells.size and (wells[-1] >= n_clusters or wells[0] < 0):
+            raise IndexError("Requested cluster %i is out of range.  Highest on this "
+                             "tile is %i." % (int(wells[-1]), n_clusters - 1))
         tb = TileBatch(sc, len(chunk), len(cycle_list), n_clusters)
-        seq_bytes = {}
-        try:
-            if wells.size and (wells[-1] >= n_clusters or wells[0] < 0):
-                raise IndexError("Requested cluster %i is out of range.  Highest on this "
-                                 "tile is %i." % (int(wells[-1]), n_clusters - 1))
+        live.append(tb)
+        # ingest: every (tile, cycle) file is gunzipped into pinned memory and copied to the GPU
+        # by libwelldup (wd_load_bcl_gz).  Runs without .bcl.gz files are NovaSeq runs: the
+        # tile's block of the lane/surface .cbcl is gunzipped on the host and expanded on the
+        # GPU (wd_load_cbcl_tile), which needs the tile's filter first.
+        filt = [pool.submit(sc.load_filter, h.filter_file, tb.filter_ptr(i), n_clusters)
+                for i, h in enumerate(handles)]
 
-            # ingest: every (tile, cycle) file is gunzipped into pinned memory and copied to
-            # the GPU by libwelldup (wd_load_bcl_gz; the ctypes call releases the GIL, so the
-            # pool's threads overlap gunzip, PCIe and each other).  Runs without .bcl.gz files
-            # are NovaSeq runs: the tile's block of the lane/surface .cbcl is gunzipped on the
-            # host and expanded on the GPU (wd_load_cbcl_tile), which needs the filter first.
-            for i, h in enumerate(handles):
-                sc.load_filter(h.filter_file, tb.filter_ptr(i), n_clusters)
+        def load(i, c):
+            try:
+                sc.load_bcl_gz(handles[i].plane_path(cycle_list[c]), tb.plane_ptr(i, c), n_clusters)
+            except FileNotFoundError:       # only a missing file: a corrupt one is reported as such
+                filt[i].result()
+                sc.load_cbcl_tile(handles[i].cbcl_path(cycle_list[c]), int(handles[i].tile),
+                                  tb.filter_ptr(i), n_clusters, tb.plane_ptr(i, c))
+        planes = [pool.submit(load, i, c) for i in range(len(handles)) for c in range(len(cycle_list))]
+        return _Loading(chunk, handles, tb, filt + planes)
 
-            def load(job):
-                i, c = job
-                try:
-                    sc.load_bcl_gz(handles[i].plane_path(cycle_list[c]), tb.plane_ptr(i, c), n_clusters)
-                except FileNotFoundError:
-                    sc.load_cbcl_tile(handles[i].cbcl_path(cycle_list[c]), int(handles[i].tile),
-                                      tb.filter_ptr(i), n_clusters, tb.plane_ptr(i, c))
-            jobs = [(i, c) for i in range(len(handles)) for c in range(len(cycle_list))]
-            list(pool.map(load, jobs))
-            for i, h in enumerate(handles):
+    def release(tb):
+        live.remove(tb)
+        tb.free()
+
+    try:
+        nxt = start(batches[0]) if batches else None
+        for bi in range(len(batches)):
+            cur, nxt = nxt, None
+            cur.wait()
+            if overlap and bi + 1 < len(batches):
+                nxt = start(batches[bi + 1])           # loads while this batch is scanned
+            chunk, tb = cur.chunk, cur.tb
+            n_clusters = tb.N
+            seq_bytes = {}
+            for i in range(len(chunk)):
                 if want_log and wells.size:
                     # only the bytes of wells some target touches come back, for the stderr log
                     seq_bytes[i] = sc.gather_wells([tb.plane_ptr(i, c) for c in range(len(cycle_list))],
@@ -165,25 +204,30 @@ def scan_lane(sc: Scanner, reader, lane, tiles, cycle_list, mode, k, csr, wells,
                 sc.hitlog_enable(0)
                 order = np.lexsort((hits["slot"], hits["target"], hits["tile"]))
                 hits = hits[order]
-        finally:
-            tb.free()
-        for i, t in enumerate(chunk):
-            counts[t] = report.TileCounts.from_block(blocks[i], levels)
-            if want_log:
-                lines = ["Reading tile %s in lane %s" % (t, lane),
-                         "Got %i sequences from %i contiguous cycle ranges." % (
-                             wells.size * want_log, want_log)]
-                sel = hits[hits["tile"] == i]
-                sb = seq_bytes.get(i)
-                for h in sel:
-                    c, w = int(centre[h["target"]]), int(nbr[h["slot"]])
-                    cs = _decode(sb[np.searchsorted(wells, c)])
-                    ws = _decode(sb[np.searchsorted(wells, w)])
-                    lines.append("center seq at {:>07}: {}".format(c, cs))
-                    lines.append("well seq at   {:>07}: {}".format(w, ws))
-                    lines.append("edit distance: {}".format(int(h["dist"])))
-                logs[t] = lines
-    pool.shutdown()
+            release(tb)
+            for i, t in enumerate(chunk):
+                counts[t] = report.TileCounts.from_block(blocks[i], levels)
+                if want_log:
+                    lines = ["Reading tile %s in lane %s" % (t, lane),
+                             "Got %i sequences from %i contiguous cycle ranges." % (
+                                 wells.size * want_log, want_log)]
+                    sel = hits[hits["tile"] == i]
+                    sb = seq_bytes.get(i)
+                    for h in sel:
+                        c, w = int(centre[h["target"]]), int(nbr[h["slot"]])
+                        cs = _decode(sb[np.searchsorted(wells, c)])
+                        ws = _decode(sb[np.searchsorted(wells, w)])
+                        lines.append("center seq at {:>07}: {}".format(c, cs))
+                        lines.append("well seq at   {:>07}: {}".format(w, ws))
+                        lines.append("edit distance: {}".format(int(h["dist"])))
+                    logs[t] = lines
+            if not overlap and bi + 1 < len(batches):
+                nxt = start(batches[bi + 1])
+    finally:
+        # queued loads are dropped, running ones finish - only then may their targets go
+        pool.shutdown(wait=True, cancel_futures=True)
+        for tb in list(live):
+            release(tb)
     return counts, logs
 
 
@@ -220,7 +264,7 @@ def main(argv=None):
             torch.cuda.set_device(device)
             tdist.init_process_group("nccl", device_id=torch.device("cuda", device))
         else:
-            tdist.init_process_group("gloo")
+            tdist.init_process_group("gloo")            # gloo; "wd": the bootstrap channel of the unique id
     levels = args.level
     out_fh = open(args.output, "w") if (args.output and rank == 0) else None
     try:
@@ -233,30 +277,56 @@ def main(argv=None):
             else:
                 n_targets = len(targets)
                 sc.set_targets(*csr)
-            for lane in lanes:
-                mine = wdist.shard(tiles, rank, world)
-                counts, logs = scan_lane(sc, reader, lane, mine, cycle_list, mode, k, csr, wells,
-                                         max(1, args.tile_batch), args.threads,
-                                         0 if (args.quiet or args.all_wells) else len(cycles))
-                if world > 1:
-                    import torch
-                    import torch.distributed as tdist
-                    rows = np.array([[counts[t].targets] + counts[t].wells + counts[t].dups + counts[t].hit
-                                     + counts[t].first + counts[t].last for t in mine],
-                                    dtype=np.int64).reshape(len(mine), 1 + 5 * levels)
-                    dev = torch.device("cuda", device) if args.dist_backend == "nccl" else torch.device("cpu")
-                    full = wdist.merge_blocks(torch.from_numpy(rows).to(dev), len(tiles), rank, world,
-                                              device=dev).cpu().numpy()
-                    counts = {t: report.TileCounts.from_block(full[i], levels) for i, t in enumerate(tiles)}
-                    gathered = [None] * world
-                    tdist.all_gather_object(gathered, logs)
-                    logs = {t: lines for part in gathered for t, lines in part.items()}
+            # (lane, tile) items are independent (count_well_duplicates.py:207-226): the flat list
+            # is block-partitioned over the ranks, every rank scans its share lane by lane, and ONE
+            # all-reduce of the [items, 1 + 5 levels] counter block (plus one gather of the log
+            # lines) makes rank 0 hold what the single-process run holds
+            lanes = list(lanes)
+            items = [(lane, t) for lane in lanes for t in tiles]
+            mine = wdist.shard(items, rank, world)
+            ncnt = 1 + 5 * levels
+            rows = np.zeros((len(mine), ncnt), dtype=np.int64)
+            logs, err = {}, None
+
+            def emit(lane, block_of):       # a finished lane: its log lines, then its report (:269)
+                counts = {t: report.TileCounts.from_block(block_of(t), levels) for t in tiles}
+                for t in tiles:
+                    for line in logs.get((lane, t), ()):
+                        log(line)
+                report.write_report(lane, n_targets, counts, verbose=not args.summary_only,
+                                    strict=args.strict, out=out_fh)
+
+            try:
+                for lane in lanes:
+                    lane_tiles = [t for (ln, t) in mine if ln == lane]
+                    if not lane_tiles:
+                        continue
+                    counts, lane_logs = scan_lane(sc, reader, lane, lane_tiles, cycle_list, mode, k, csr, wells,
+                                                  max(1, args.tile_batch), args.threads,
+                                                  0 if (args.quiet or args.all_wells) else len(cycles),
+                                                  overlap=not args.serial_ingest)
+                    for i, (ln, t) in enumerate(mine):
+                        if ln == lane:
+                            c = counts[t]
+                            rows[i] = [c.targets] + c.wells + c.dups + c.hit + c.first + c.last
+                    logs.update({(lane, t): lines for t, lines in lane_logs.items()})
+                    if world == 1:          # as the reference: a lane is reported when it is done
+                        emit(lane, lambda t: rows[items.index((lane, t))])
+            except Exception as e:          # noqa: BLE001 - re-raised below, on every rank
+                err = e
+            if world > 1:
+                # a rank that failed must not leave the others waiting in the collective
+                failed = wdist.any_rank_failed(err is not None, world, backend=args.dist_backend, device=device)
+                if failed:
+                    raise err if err is not None else RuntimeError("another rank failed; see its message")
+                full = wdist.merge_blocks(rows, len(items), rank, world, backend=args.dist_backend,
+                                          device=device, scanner=sc)
+                logs = wdist.gather_dicts(logs, world)
                 if rank == 0:
-                    for t in tiles:
-                        for line in logs.get(t, ()):
-                            log(line)
-                    report.write_report(lane, n_targets, counts, verbose=not args.summary_only,
-                                        strict=args.strict, out=out_fh)
+                    for lane in lanes:
+                        emit(lane, lambda t: full[items.index((lane, t))])
+            elif err is not None:
+                raise err
     finally:
         if out_fh:
             out_fh.close()

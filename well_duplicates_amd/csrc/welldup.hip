@@ -101,7 +101,7 @@ bool rccl_load(std::string &err)
     return true;
 }
 
-int g_create_status = WD_OK;
+thread_local int g_create_status = WD_OK;     // of the calling thread's last wd_create
 
 }  // namespace
 
@@ -278,10 +278,7 @@ void drain_events(wd_ctx *ctx)
 constexpr int kHamShapes[][2] = {{2, 4}, {3, 4}, {4, 4}, {4, 8}, {8, 8}};
 // first-round depth per band half-width H: where ~2-4 % of random neighbours are still alive
 // under LevState::alive's lag-free criterion (k = 2H or 2H+1)
-#ifndef WD_LEV_FIRST_H1
-#define WD_LEV_FIRST_H1 7
-#endif
-constexpr int lev_first(int H) { return H == 1 ? WD_LEV_FIRST_H1 : H == 2 ? 10 : H == 3 ? 13 : H == 4 ? 16 : H <= 6 ? 20 : 24; }
+constexpr int lev_first(int H) { return H == 1 ? 7 : H == 2 ? 10 : H == 3 ? 13 : H == 4 ? 16 : H <= 6 ? 20 : 24; }
 constexpr int kLevB2 = 8;
 
 template <bool STRIDED>
@@ -398,8 +395,6 @@ int ensure_dense_tables(wd_ctx *ctx)
     const size_t n_el = (size_t)std::max<long long>(1, total);
     WD_HIP(ctx, hipMalloc(&ctx->d_nbr_t, n_el * sizeof(int16_t)));
     ctx->nbr_t16 = true;
-    if (!ctx->d_tblflags)
-        WD_HIP(ctx, hipMalloc((void **)&ctx->d_tblflags, 2 * sizeof(uint32_t)));
     if (groups > 0) {
         uint32_t flags[2] = {0, 0};
         WD_HIP(ctx, hipMemsetAsync(ctx->d_tblflags, 0, sizeof(flags), ctx->stream));
@@ -700,6 +695,8 @@ const char *wd_strerror(int code)
     case WD_ERR_NO_WELLS: return "a cluster has no wells at some level";
     case WD_ERR_IO: return "cannot read file";
     case WD_ERR_FORMAT: return "file header does not match the tile";
+    case WD_ERR_CORRUPT: return "compressed data is corrupt";
+    case WD_ERR_TRUNCATED: return "compressed file ended before the end-of-stream marker";
     default: return "unknown error";
     }
 }
@@ -732,6 +729,7 @@ wd_ctx *wd_create(int device_id)
     if (hipSetDevice(device_id) != hipSuccess ||
         hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking) != hipSuccess ||
         hipMalloc((void **)&ctx->d_status, sizeof(uint32_t)) != hipSuccess ||
+        hipMalloc((void **)&ctx->d_tblflags, 2 * sizeof(uint32_t)) != hipSuccess ||
         hipMalloc((void **)&ctx->d_rare, sizeof(ScanRare)) != hipSuccess ||
         hipHostMalloc((void **)&ctx->h_status, sizeof(uint32_t), hipHostMallocDefault) != hipSuccess ||
         hipMalloc((void **)&ctx->d_hit_count, sizeof(unsigned long long)) != hipSuccess) {
@@ -1069,7 +1067,10 @@ int wd_scan_async(wd_ctx *ctx, int n_tiles, int L, int mode, int k, const uint8_
         kk = 0;
     } else if (mode == WD_MODE_LEVENSHTEIN) {
         if (k >= L) {
-            kk = L;                 // every equal-length pair is within L substitutions
+            // every equal-length pair is within L substitutions: a Hamming problem - unless the
+            // hit log wants the true (possibly smaller) edit distance of every pair (:260-262)
+            kk = L;
+            lev = ctx->hit_cap > 0 && L >= 2 && lev_generic_lds_bytes(L, L / 2) <= 64 * 1024;
         } else if (k >= 2) {
             lev = true;
         }                            // k <= 1: equal lengths, so one edit is one substitution
@@ -1463,7 +1464,7 @@ int wd_targets_from_coords(wd_ctx *ctx, const int32_t *x, const int32_t *y, int6
         WD_GEN_HIP(hipMemcpy(d_centre, iota.data(), (size_t)T * 4, hipMemcpyHostToDevice));
     }
     WD_GEN_HIP(hipMalloc((void **)&d_counts, std::max<size_t>(1, (size_t)T * levels) * 4));
-    WD_GEN_HIP(hipMemsetAsync(ctx->d_status, 0, sizeof(uint32_t), ctx->stream));
+    WD_GEN_HIP(hipMemsetAsync(ctx->d_tblflags, 0, sizeof(uint32_t), ctx->stream));
     GenArgs a;
     a.x = d_x;
     a.y = d_y;
@@ -1476,7 +1477,7 @@ int wd_targets_from_coords(wd_ctx *ctx, const int32_t *x, const int32_t *y, int6
     a.counts = d_counts;
     a.lvl_off = nullptr;
     a.nbr = nullptr;
-    a.status = ctx->d_status;
+    a.status = ctx->d_tblflags;
     std::vector<int32_t> off((size_t)T * (levels + 1) + 1, 0);
     int64_t P = 0;
     if (T > 0) {
@@ -1484,10 +1485,10 @@ int wd_targets_from_coords(wd_ctx *ctx, const int32_t *x, const int32_t *y, int6
         WD_GEN_HIP(hipGetLastError());
         std::vector<int32_t> counts((size_t)T * levels);
         WD_GEN_HIP(hipMemcpyAsync(counts.data(), d_counts, counts.size() * 4, hipMemcpyDeviceToHost, ctx->stream));
-        WD_GEN_HIP(hipMemcpyAsync(ctx->h_status, ctx->d_status, 4, hipMemcpyDeviceToHost, ctx->stream));
+        WD_GEN_HIP(hipMemcpyAsync(ctx->h_status, ctx->d_tblflags, 4, hipMemcpyDeviceToHost, ctx->stream));
         WD_GEN_HIP(hipStreamSynchronize(ctx->stream));
         if (*ctx->h_status & 2u) {
-            (void)hipMemsetAsync(ctx->d_status, 0, sizeof(uint32_t), ctx->stream);
+            (void)hipMemsetAsync(ctx->d_tblflags, 0, sizeof(uint32_t), ctx->stream);
             return bail(WD_ERR_NO_WELLS, "Got no wells for some cluster at some level");
         }
         for (int t = 0; t < T; t++) {
@@ -1508,10 +1509,10 @@ int wd_targets_from_coords(wd_ctx *ctx, const int32_t *x, const int32_t *y, int6
         a.nbr = d_nbr;
         hipLaunchKernelGGL((k_gen_rings<true>), dim3(T), dim3(kBlock), 0, ctx->stream, a);
         WD_GEN_HIP(hipGetLastError());
-        WD_GEN_HIP(hipMemcpyAsync(ctx->h_status, ctx->d_status, 4, hipMemcpyDeviceToHost, ctx->stream));
+        WD_GEN_HIP(hipMemcpyAsync(ctx->h_status, ctx->d_tblflags, 4, hipMemcpyDeviceToHost, ctx->stream));
         WD_GEN_HIP(hipStreamSynchronize(ctx->stream));
         if (*ctx->h_status & 4u) {
-            (void)hipMemsetAsync(ctx->d_status, 0, sizeof(uint32_t), ctx->stream);
+            (void)hipMemsetAsync(ctx->d_tblflags, 0, sizeof(uint32_t), ctx->stream);
             return bail(WD_ERR_UNSUPPORTED, "a target has more than 2048 wells inside the outermost ring");
         }
     }
@@ -1709,13 +1710,14 @@ int wd_gunzip(const uint8_t *src, size_t src_len, uint8_t *dst, size_t dst_cap, 
             if (zs.avail_in == 0)
                 break;
             if (inflateReset(&zs) != Z_OK) {
-                rc = WD_ERR_IO;
+                rc = WD_ERR_CORRUPT;
                 break;
             }
             continue;
         }
         if (zr != Z_OK || zs.avail_out == 0 || zs.avail_in == 0) {
-            rc = WD_ERR_IO;                                 // corrupt, too long for dst, or truncated
+            // corrupt; too long for dst; truncated
+            rc = zr != Z_OK ? WD_ERR_CORRUPT : zs.avail_out == 0 ? WD_ERR_IO : WD_ERR_TRUNCATED;
             break;
         }
     }
@@ -1742,7 +1744,7 @@ int wd_load_bcl_gz(wd_ctx *ctx, const char *path, uint8_t *dst_dev, int64_t n_cl
     if (rc)
         return rc;
     size_t produced = 0;
-    bool bad = false;
+    bool bad = false, truncated = false;
     if (!ctx->fast_inflate ||
         !fast_gunzip(raw, raw_len, lease.slot->pinned, want + 64 + 274, &produced) || produced > want + 64) {
         // zlib: gunzip (possibly several concatenated members) straight into the pinned buffer
@@ -1770,13 +1772,19 @@ int wd_load_bcl_gz(wd_ctx *ctx, const char *path, uint8_t *dst_dev, int64_t n_cl
                 bad = zr != Z_OK;                          // avail_out == 0: more data than a plane
                 break;
             }
-            if (zs.avail_in == 0)
-                break;                                     // truncated stream
+            if (zs.avail_in == 0) {
+                truncated = true;                          // the stream ends before its end marker
+                break;
+            }
         }
         inflateEnd(&zs);
     }
+    // what gzip.open(..).read() raises in the reference (bcl_direct_reader.py:208-209): BadGzipFile /
+    // zlib.error for corrupt data, EOFError for a truncated file - not "file not found"
     if (bad)
-        return WD_ERR_IO;
+        return WD_ERR_CORRUPT;
+    if (truncated)
+        return WD_ERR_TRUNCATED;
     if (produced < 4)
         return WD_ERR_FORMAT;
     uint32_t header;
@@ -1896,7 +1904,7 @@ int wd_load_cbcl_tile(wd_ctx *ctx, const char *path, int tile_number, const uint
         produced = (size_t)(zs.next_out - sl->pinned);
         inflateEnd(&zs);
         if (zr != Z_STREAM_END && zr != Z_OK && zr != Z_BUF_ERROR)
-            return WD_ERR_IO;
+            return WD_ERR_CORRUPT;
     }
     const long long n_records = (long long)produced * 2;
     const int chunks = (int)((n_clusters + kCbclChunk - 1) / kCbclChunk);

@@ -27,9 +27,13 @@ def compare_mode(edit_distance: int, hamming: bool):
     return (MODE_HAMMING if hamming else MODE_LEVENSHTEIN), int(edit_distance)
 
 
-def _raise(lib, ctx, rc: int):
+def _raise(lib, ctx, rc: int, path: Optional[str] = None):
+    """Raise what the reference would: the exception classes of include/welldup.h's table.
+    `path` names the file a loader was reading (one of thousands per batch)."""
     detail = lib.wd_last_error(ctx).decode() if ctx else ""
     msg = "%s%s" % (lib.wd_strerror(rc).decode(), (": " + detail) if detail else "")
+    if path is not None:
+        msg = "%s: %s" % (msg, path)
     if rc == _lib.ERR_INDEX:
         raise IndexError(msg)            # bcl_direct_reader.py:186-192
     if rc == _lib.ERR_EMPTY_LEVEL:
@@ -40,6 +44,22 @@ def _raise(lib, ctx, rc: int):
         raise MemoryError(msg)
     if rc == _lib.ERR_IO:
         raise FileNotFoundError(msg)      # bcl_direct_reader.py:207-216
+    if rc == _lib.ERR_TRUNCATED:
+        raise EOFError(msg)               # gzip.open(..).read() on a file that ends early (:208-209)
+    if rc == _lib.ERR_CORRUPT:
+        # ... on bad data: BadGzipFile when it is not a gzip file at all, else zlib.error
+        import gzip
+        import zlib
+        magic = b""
+        try:
+            if path is not None and not path.endswith(".cbcl"):
+                with open(path, "rb") as fh:
+                    magic = fh.read(2)
+        except OSError:
+            pass
+        if magic and magic != b"\x1f\x8b":
+            raise gzip.BadGzipFile(msg)
+        raise zlib.error(msg)
     if rc == _lib.ERR_FORMAT:
         raise AssertionError(msg)         # bcl_direct_reader.py:151, :236, :338
     raise RuntimeError(msg)
@@ -219,19 +239,19 @@ class Scanner:
         """gunzip a .bcl.gz straight into device memory (thread-safe, releases the GIL)."""
         rc = self._lib.wd_load_bcl_gz(self._ctx, os.fsencode(path), ctypes.c_void_p(dst), int(n_clusters))
         if rc != _lib.OK:
-            _raise(self._lib, None, rc)
+            _raise(self._lib, None, rc, path)
 
     def load_filter(self, path: str, dst: int, n_clusters: int):
         rc = self._lib.wd_load_filter(self._ctx, os.fsencode(path), ctypes.c_void_p(dst), int(n_clusters))
         if rc != _lib.OK:
-            _raise(self._lib, None, rc)
+            _raise(self._lib, None, rc, path)
 
     def load_cbcl_tile(self, path: str, tile: int, filter_dev: int, n_clusters: int, dst: int):
         """One tile's block of a NovaSeq .cbcl file -> byte plane on the device (thread-safe)."""
         rc = self._lib.wd_load_cbcl_tile(self._ctx, os.fsencode(path), int(tile),
                                          ctypes.c_void_p(filter_dev), int(n_clusters), ctypes.c_void_p(dst))
         if rc != _lib.OK:
-            _raise(self._lib, None, rc)
+            _raise(self._lib, None, rc, path)
 
     def gather_wells(self, plane_ptrs: Sequence[int], idx, n_clusters: int) -> np.ndarray:
         """uint8 [len(idx), L]: bytes of the given wells over the L planes."""

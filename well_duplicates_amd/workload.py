@@ -17,6 +17,11 @@ from . import cluster_indexes, synth
 HISEQ_4000 = "hiseq_4000"
 HISEQ_X = "hiseq_x"
 HISEQ4000_ROWS, HISEQ4000_COLS = 2743, 1571      # SURVEY.md section 8d geometry
+# NovaSeq: 4 091 904 wells per tile (cbcl_read.py:77-78).  The reference never states the grid's
+# shape; 2664 x 1536 is the factorisation used here, on the same honeycomb pitch.  A lane has
+# 2 surfaces x 6 swaths x 78 tiles (--stype 2678 -> 936 tile ids).
+NOVASEQ_ROWS, NOVASEQ_COLS = 2664, 1536
+NOVASEQ_STYPE = "2678"
 
 
 def tiles_for_stype(stype: str) -> List[str]:
