@@ -134,4 +134,4 @@ def _lev2_screen(a: int, b: int) -> int:
     up = fold(ah ^ b) & m0
     dn = fold(al ^ b) & m0
     pop = lambda v: bin(v).count("1")
-    return min((pop(m0) + 1) >> 1, pop(up), pop(dn))
+    return min((pop(m0) - 1) & 0xFFFFFFFF, pop(up), pop(dn))

@@ -551,7 +551,7 @@ int launch_dense(wd_ctx *ctx, const ScanArgs &a, dim3 grid, int n_tiles, int64_t
     long long q_per = ctx->dense_queue_cap > 0 ? ctx->dense_queue_cap : (lev2 ? 32 : 16);
     // LDS of a k_dense_pairs wave: its signature windows, then 8 bytes per queue entry
     const long long win_bytes = (long long)kWinBufs * d.win_dwords * sizeof(uint32_t);
-    q_per = std::max<long long>(1, std::min<long long>(q_per, ((64 * 1024 - 256) / kWaves - win_bytes) / 8));
+    q_per = std::max<long long>(1, std::min<long long>(q_per, kWave));      // one queue entry per lane at most
     d.q_per = (int)q_per;
     d.mw_stride = (((N + 31) / 32) + kMarkBlock - 1) / kMarkBlock * kMarkBlock;
     const size_t mark_words = (size_t)n_tiles * d.mw_stride;
@@ -583,8 +583,8 @@ int launch_dense(wd_ctx *ctx, const ScanArgs &a, dim3 grid, int n_tiles, int64_t
     // Checking one survivor against the planes touches 2 (L - 10) cache lines, one per plane and
     // well; packing touches at most one line per plane and MARKED well (wells of a line share it,
     // lines without a marked well are skipped) and leaves a 64-byte row per marked well: never
-    // more lines than the byte-by-byte check, so rows are used whenever there is a survivor.
-    d.pack_threshold = 1;
+    // more lines than the byte-by-byte check, so rows are used whenever there is a survivor
+    // (dense_packed, scan_dense.inc).
     d.cand = ctx->d_cand;
     WD_HIP(ctx, hipMemsetAsync(ctx->d_cand, 0, (kDenseSlots + 1) * sizeof(uint32_t), ctx->stream));
     d.sig = ctx->d_sig;
@@ -613,7 +613,8 @@ int launch_dense(wd_ctx *ctx, const ScanArgs &a, dim3 grid, int n_tiles, int64_t
         hipLaunchKernelGGL((k_dense_sig<false, true>), grid1, dim3(kBlock), 0, ctx->stream, d);
     else
         hipLaunchKernelGGL((k_dense_sig<false, false>), grid1, dim3(kBlock), 0, ctx->stream, d);
-    const size_t q_lds = (size_t)kWaves * ((size_t)win_bytes + (size_t)d.q_per * sizeof(uint2));
+    // LDS of a compare-stage wave: its windows, one queue per tile of the chunk, their counts
+    const size_t q_lds = (size_t)kWaves * ((size_t)win_bytes + 4 * ((size_t)tile_chunk * (2 * d.q_per + 1) + (tile_chunk & 1)));
     hipLaunchKernelGGL(k_dense_counts, dim3((unsigned)((a.T + 4 * kBlock - 1) / (4 * kBlock)),
                                             (unsigned)((n_tiles + tile_chunk - 1) / tile_chunk)),
                        dim3(kBlock), 0, ctx->stream, d);
@@ -637,7 +638,8 @@ int launch_dense(wd_ctx *ctx, const ScanArgs &a, dim3 grid, int n_tiles, int64_t
         WD_LAUNCH_PAIRS(2);
 #undef WD_LAUNCH_PAIRS
     const unsigned mark_blocks = (unsigned)((n_groups + kWave * kWaves - 1) / (kWave * kWaves));
-    hipLaunchKernelGGL(k_dense_mark, dim3(mark_blocks, (unsigned)n_tiles), dim3(kBlock), 0, ctx->stream, d);
+    if (lev2)
+        hipLaunchKernelGGL(k_dense_mark, dim3(mark_blocks, (unsigned)n_tiles), dim3(kBlock), 0, ctx->stream, d);
     if (d.rows) {
         hipLaunchKernelGGL(k_dense_rank_words, dim3((unsigned)(d.mw_stride / kMarkBlock), (unsigned)n_tiles), dim3(kMarkBlock),
                            0, ctx->stream, d);
@@ -1176,7 +1178,7 @@ int wd_scan_async(wd_ctx *ctx, int n_tiles, int L, int mode, int k, const uint8_
     if (ws == 4 && ctx->dense_kernel < 0)
         use_dense = false;                                   // the dense path reads planes
     const int chunks = (ctx->T + ctx->tpb - 1) / ctx->tpb;
-    const int tile_chunk = std::max(1, std::min(ctx->dense_tile_chunk, n_tiles));
+    const int tile_chunk = std::max(1, std::min({ctx->dense_tile_chunk, n_tiles, 16}));    // (LDS: one survivor queue per tile)
     // dense grid: 8 XCDs x (target blocks per XCD) x tile_chunk x (chunks of tiles), see k_dense_pairs
     const long long dense_bpt = (ctx->T + kBlock - 1) / kBlock;
     const long long dense_blocks = (long long)kXcds * ((dense_bpt + kXcds - 1) / kXcds) *
