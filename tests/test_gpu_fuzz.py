@@ -98,3 +98,106 @@ def test_fuzz(seed):
                     assert (got == want[i][0]).all(), (seed, mode, k, opts, i)
                     assert (blocks_to_reference(blocks[i], levels) == want[i][1]).all(), (seed, mode, k, opts)
         tb.free()
+
+
+# ---- the dense path's window groups -------------------------------------------------------
+# Consecutive centres on a small grid with a perturbed ring pattern: wells missing from some
+# targets' rings (membership bits), an offset that sits in different rings for different targets
+# ((ring, offset) union), tile edges (union elements that point outside the tile for some lanes),
+# a ring listed out of order or a well listed twice (the group must fall back to the gathers),
+# a partial last group, several tile chunks, tiny survivor queues (overflow paths).
+N_WIN_SEEDS = int(os.environ.get("WD_FUZZ_WINDOW_SEEDS", "10"))
+
+
+def _grid_targets(rng, rows, cols, c_first, T, levels, n_off, p_drop, p_flip, p_mess):
+    offs = set()
+    while len(offs) < n_off:
+        dr, dc = int(rng.integers(-3, 4)), int(rng.integers(-7, 8))
+        if (dr, dc) != (0, 0):
+            offs.add((dr, dc))
+    offs = sorted(offs)
+    base_level = {o: int(rng.integers(0, levels)) for o in offs}
+    n = rows * cols
+    centre = np.arange(c_first, c_first + T, dtype=np.int32)
+    lvl_off = np.zeros((T, levels + 1), dtype=np.int32)
+    nbr, pos = [], 0
+    for t, c in enumerate(centre):
+        r0, c0 = divmod(int(c), cols)
+        rings = [[] for _ in range(levels)]
+        for (dr, dc) in offs:
+            r, cc = r0 + dr, c0 + dc
+            if not (0 <= r < rows and 0 <= cc < cols) or rng.random() < p_drop:
+                continue
+            lev = base_level[(dr, dc)]
+            if rng.random() < p_flip:
+                lev = int(rng.integers(0, levels))
+            rings[lev].append(r * cols + cc)
+        lvl_off[t, 0] = pos
+        for l in range(levels):
+            ring = sorted(set(rings[l]))
+            if not ring:                                   # the reference asserts non-empty rings (:249)
+                ring = [int(c) + 1 if int(c) + 1 < n else int(c) - 1]
+            if rng.random() < p_mess:
+                if rng.random() < 0.5 and len(ring) > 1:
+                    ring = ring[::-1]                      # not ascending
+                else:
+                    ring = ring + [ring[0]]                # a well twice
+            nbr.extend(ring)
+            pos += len(ring)
+            lvl_off[t, l + 1] = pos
+    return centre, lvl_off, np.asarray(nbr, dtype=np.int32)
+
+
+@pytest.mark.parametrize("seed", range(N_WIN_SEEDS))
+def test_fuzz_window_groups(seed):
+    rng = np.random.default_rng(7000 + seed)
+    rows, cols = int(rng.integers(8, 30)), int(rng.choice([64, 70, 97, 128, 200, 257]))
+    n = rows * cols
+    levels = int(rng.integers(1, 6))
+    L = int(rng.choice([3, 9, 10, 11, 16, 17, 24, 40, 150]))
+    T = int(rng.choice([n, n - 1, n // 2 + 7, 64, 65, 129]))
+    T = max(1, min(T, n))
+    c_first = int(rng.integers(0, n - T + 1))
+    p_mess, p_flip = float(rng.choice([0.0, 0.0, 0.003])), float(rng.choice([0.0, 0.05]))
+    centre, lvl_off, nbr = _grid_targets(rng, rows, cols, c_first, T, levels, int(rng.choice([4, 12, 36, 60, 90])),
+                                         float(rng.choice([0.0, 0.02, 0.3])), p_flip, p_mess)
+    spec = synth.SynthSpec(seed=300 + seed, n_clusters=n, row=cols,
+                           plant_per_64k=int(rng.choice([0, 2000, 20000, 65536])),
+                           nocall_per_64k=int(rng.choice([0, 300, 5000])),
+                           pass_per_64k=int(rng.choice([65536, 45000, 20000])), plant_far=bool(rng.integers(0, 2)))
+    n_tiles = int(rng.choice([1, 3, 5]))
+    tiles = [(1 + i % 3, 1101 + i) for i in range(n_tiles)]
+    cycles = list(range(1, 1 + L))
+    print("window fuzz seed %d: %dx%d T=%d first=%d levels=%d L=%d tiles=%d" % (seed, rows, cols, T, c_first, levels, L, n_tiles))
+    with Scanner(0) as sc:
+        sc.set_targets(centre, lvl_off, nbr)
+        tb = TileBatch(sc, n_tiles, L, n)
+        tb.fill_synthetic(spec, tiles, cycles)
+        host = [([synth.plane_bytes(spec, lane, tile, c) for c in cycles], synth.filter_bytes(spec, lane, tile))
+                for lane, tile in tiles]
+        try:
+            for mode, k in ((0, 0), (1, 1), (1, 2), (2, 2)):
+                want = []
+                for planes, filt in host:
+                    valid, dups, lens, _ = oracle.count_tile(planes, filt, centre, lvl_off, nbr, mode, k)
+                    want.append((np.where(valid[:, None] == 1, dups, -1), oracle.tally_tile(valid, dups, lens)))
+                for trial in range(3):
+                    opts = {"dense_kernel": 1,
+                            "dense_windows": int(rng.integers(0, 2)) if trial else 1,
+                            "dense_tile_chunk": int(rng.choice([1, 2, 3, 8])),
+                            "dense_queue_cap": int(rng.choice([0, 0, 1, 3, 64])),
+                            "dense_pack": int(rng.choice([-1, 0, 1])) if trial else -1}
+                    for name, v in opts.items():
+                        sc.set_option(name, v)
+                    blocks, pt = tb.count(mode, k, per_target=True)
+                    # clean input (with ring flips a union of (ring, offset) pairs may outgrow the 128
+                    # elements a window group holds): the path under test is the one that ran
+                    if p_mess == 0.0 and p_flip == 0.0 and T >= 128:
+                        assert sc.get_option("dense_window_groups") >= (T // 64) // 2, sc.get_option("dense_window_groups")
+                    for i in range(n_tiles):
+                        got = pt[i].astype(np.int64)
+                        got[got == INVALID_TARGET] = -1
+                        assert (got == want[i][0]).all(), (seed, mode, k, opts, i)
+                        assert (blocks_to_reference(blocks[i], levels) == want[i][1]).all(), (seed, mode, k, opts)
+        finally:
+            tb.free()
