@@ -267,6 +267,7 @@ def e2e_probe(device, n_tiles, rows, cols, centre, lvl_off, nbr, cycles=50, thre
         run([])                                               # page cache, allocator, first-use costs
         best, text = min(run([]) for _ in range(2))
         serial, text_s = min(run(["--serial-ingest"]) for _ in range(2))
+        inter, text_i = min(run(["--layout", "interleaved"]) for _ in range(2))
         plane_bytes = n_tiles * cycles * n
         return {"what": "count_well_duplicates CLI (-e 2 Levenshtein, %d targets x %d levels, -q -S) on %d full-size "
                         "tiles x %d cycles of .bcl.gz files (gzip -6, 7 quality bins), warm page cache; two batches "
@@ -276,7 +277,8 @@ def e2e_probe(device, n_tiles, rows, cols, centre, lvl_off, nbr, cycles=50, thre
                 "plane_gb_per_s": round(plane_bytes / best / 1e9, 3),
                 "serial_ingest_seconds": round(serial, 4),
                 "overlap_gain": round(serial / best, 3) if best > 0 else None,
-                "same_report": text == text_s, "run_dir_write_s": round(write_s, 1),
+                "interleaved_layout_seconds": round(inter, 4),
+                "same_report": text == text_s == text_i, "run_dir_write_s": round(write_s, 1),
                 "reference_s_per_tile": 7.9,
                 "reference_note": "unmodified reference, 1 core, same geometry, --hamming -e 0 (BASELINE.md; measured in "
                                   "the build container, not on this box)"}
@@ -505,6 +507,20 @@ def main():
                  "alg_bytes_over_peak": round(b_il / (i_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                  "same_counters_as_plane_layout": same},
                 "il_T%d_l%d_L%d" % (T, levels, L), n_il, i_ms)
+            # the reference's default metric in that layout
+            sc.set_option("well_stride", 4)
+            sc.scan_async(il.tables, n_il, L, n_clusters, MODE_LEVENSHTEIN, 2, scratch.data_ptr())
+            sc.profile_reset()
+            for _ in range(5):
+                sc.scan_async(il.tables, n_il, L, n_clusters, MODE_LEVENSHTEIN, 2, scratch.data_ptr())
+            l_ms, l_n = sc.profile_get()
+            sc.set_option("well_stride", 1)
+            sc.scan_status()
+            l_ms /= max(1, l_n)
+            other["interleaved_by_4"]["levenshtein_k2"] = with_traffic(
+                {"kernel_ms": round(l_ms, 5), "compares_per_s": round(c_il / (l_ms * 1e-3), 1),
+                 "alg_bytes_over_peak": round(b_il / (l_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
+                "il_lev2_T%d_l%d_L%d" % (T, levels, L), n_il, l_ms)
             il.free()
     sc.set_option("profile", 0)
     # BASELINE configs[4] in small: every well of a tile is a centre (device-generated rings,

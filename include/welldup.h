@@ -195,10 +195,14 @@ int wd_scan_status(wd_ctx *ctx);
  * to dst_dev; wd_load_filter does the same for a .filter file (header 0, 3, n: :148-152).
  * Both are THREAD-SAFE on one context (each call leases its own staging buffer and copy
  * stream): call them from a pool of host threads so that gunzip, PCIe and the GPU overlap.
- * wd_gather_wells returns out[w*L + c] = planes[c][idx[w]] (host output): the bytes of the
+ * wd_gather_wells returns out[w*L + c] = planes[c][idx[w]] (host output; planes[c][4 * idx[w]]
+ * while the "well_stride" option is 4): the bytes of the
  * wells the stderr duplicate log prints, without a host copy of the planes.
  */
 int wd_load_bcl_gz(wd_ctx *ctx, const char *path, uint8_t *dst_dev, int64_t n_clusters);
+/* The same into the interleaved layout (wd_interleave4): dst_dev = address of well 0's byte of this
+ * cycle inside its group of four (group base + cycle % 4), well_stride = 4; 1 = wd_load_bcl_gz. */
+int wd_load_bcl_gz_strided(wd_ctx *ctx, const char *path, uint8_t *dst_dev, int64_t n_clusters, int well_stride);
 int wd_load_filter(wd_ctx *ctx, const char *path, uint8_t *dst_dev, int64_t n_clusters);
 /* Resident layout option for the equality / Hamming scan of sampled targets.  A line of HBM holds
  * 128 wells of ONE cycle in the BCL files' plane-per-cycle layout, and the scan wants ~11

@@ -54,6 +54,23 @@ def test_cli_matches_reference(tmp_path_factory, name):
             assert err.splitlines()[0] == "Reading tile %s in lane %s" % (fx["tiles"][0], fx["lanes"][0])
 
 
+def test_cli_interleaved_layout(tmp_path_factory):
+    """--layout interleaved: the loaders write every plane into its byte lane of a group of four
+    cycles, the queue kernels (equality, Hamming, Levenshtein <= 3) scan that layout, the duplicate
+    log is gathered from it - same stdout and stderr as the reference."""
+    fx, run_dir = _run_dir(tmp_path_factory, "mid")
+    for run in fx["runs"]:
+        if run["mode"] == "levenshtein" and run["k"] > 3:
+            continue
+        out, err = _cli(fx, run_dir, run, ["--layout", "interleaved", "--tile-batch", "1"])
+        assert out == run["stdout"], run["flags"]
+        keep = ("center seq at", "well seq at", "edit distance:")
+        if "-q" not in run["flags"]:
+            assert [ln for ln in err.splitlines() if ln.startswith(keep)] == run["dup_log"], run["flags"]
+    with pytest.raises(SystemExit):                       # the dense path reads planes
+        cwd.main(["--all-wells", "-s", "hiseq_4000", "-r", run_dir, "--layout", "interleaved"])
+
+
 def test_cli_tile_batching_and_errors(tmp_path_factory):
     fx, run_dir = _run_dir(tmp_path_factory, "dead_tile")
     run = fx["runs"][0]

@@ -687,7 +687,7 @@ def test_interleaved_layout_equals_plane_layout(sc, L):
         inter.fill_synthetic(spec, tiles, list(range(L)))
         for c in range(L):
             assert (inter.download_plane(1, c) == plane.download_plane(1, c)).all()
-        for mode, k in ((0, 0), (1, 1), (1, 2), (1, 3), (1, L), (2, 1)):
+        for mode, k in ((0, 0), (1, 1), (1, 2), (1, 3), (1, L), (2, 1), (2, 2), (2, 3)):
             sc.hitlog_enable(100000)
             want = plane.count(mode, k, per_target=True)
             want_hits, want_total = sc.hitlog_fetch(100000)
@@ -697,9 +697,9 @@ def test_interleaved_layout_equals_plane_layout(sc, L):
             assert (got[0] == want[0]).all() and (got[1] == want[1]).all(), (L, mode, k)
             key = lambda h: (int(h["tile"]), int(h["target"]), int(h["slot"]), int(h["dist"]))
             assert total == want_total and sorted(map(key, hits)) == sorted(map(key, want_hits))
-        if L >= 3:
-            with pytest.raises(RuntimeError):                 # Levenshtein <= 2 reads planes only
-                inter.count(2, 2)
+        if L >= 5:
+            with pytest.raises(RuntimeError):                 # wider bands read planes only
+                inter.count(2, 4)
         sc.set_option("dense_kernel", 1)
         with pytest.raises(RuntimeError):
             inter.count(0, 0)

@@ -25,7 +25,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from well_duplicates_amd import synth, workload                     # noqa: E402
 from well_duplicates_amd.scanner import Scanner, TileBatch         # noqa: E402
 
-SPARSE = {"eq": (0, 0), "ham2": (1, 2), "lev2": (2, 2), "lev3": (2, 3), "full": (0, 0), "il": (0, 0)}
+SPARSE = {"eq": (0, 0), "ham2": (1, 2), "lev2": (2, 2), "lev3": (2, 3), "full": (0, 0), "il": (0, 0), "il_lev2": (2, 2)}
 DENSE = {"dense_eq": (0, 0), "dense_ham2": (1, 2), "dense_lev2": (2, 2)}
 
 
@@ -66,7 +66,7 @@ def main():
             sc.set_targets(centre, lvl_off, nbr)
             P = int(nbr.shape[0])
             spec = synth.SynthSpec(seed=2, n_clusters=n, row=cols)
-        interleave = 4 if a.case == "il" else 1
+        interleave = 4 if a.case.startswith("il") else 1
     for opt in a.option:
         name, val = opt.split("=")
         sc.set_option(name, int(val))

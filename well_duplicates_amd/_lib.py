@@ -70,6 +70,7 @@ PROTOTYPES = {
     "wd_scan_async": (_i, [_vp, _i, _i, _i, _i, _pp, _pp, _i64, _vp, _vp]),
     "wd_scan_status": (_i, [_vp]),
     "wd_load_bcl_gz": (_i, [_vp, ctypes.c_char_p, _vp, _i64]),
+    "wd_load_bcl_gz_strided": (_i, [_vp, ctypes.c_char_p, _vp, _i64, _i]),
     "wd_load_filter": (_i, [_vp, ctypes.c_char_p, _vp, _i64]),
     "wd_load_cbcl_tile": (_i, [_vp, ctypes.c_char_p, _i, _vp, _i64, _vp]),
     "wd_interleave4": (_i, [_vp, ctypes.POINTER(ctypes.c_void_p), _i64, _vp]),

@@ -21,7 +21,7 @@ Differences from the reference, all deliberate:
   * `-t` with a pattern that matches nothing raises the AssertionError the reference
     intends (its own message formatting raises NameError first);
   * extra flags: --device, --dist-backend, --tile-batch, --threads, --strict, -o/--output,
-    --all-wells, --slocs, --serial-ingest.
+    --all-wells, --slocs, --layout, --serial-ingest.
 """
 from __future__ import annotations
 
@@ -101,6 +101,11 @@ def parse_args(argv=None):
                         "prepare_cluster_indexes.py; the per-duplicate log is not written in this mode")
     p.add_argument("--slocs", default=None,
                    help="s.locs file for --all-wells (default: <run>/Data/Intensities/s.locs)")
+    p.add_argument("--layout", default="planes", choices=["planes", "interleaved"],
+                   help="how the scanned cycles sit in GPU memory: planes = one plane per cycle, as in the "
+                        ".bcl.gz files; interleaved = the four cycles of a group side by side per well (the "
+                        "loaders write it at no extra cost; the scan of sampled targets then touches half the "
+                        "cache lines).  interleaved: .bcl.gz runs, -e <= 3, not with --all-wells")
     p.add_argument("--serial-ingest", action="store_true",
                    help="load a batch of tiles only after the previous one has been scanned (for measuring "
                         "what the double-buffered ingest gains)")
@@ -109,6 +114,8 @@ def parse_args(argv=None):
     args = p.parse_args(argv)
     if not args.coord_file and not args.all_wells:
         p.error("the following arguments are required: -f/--coord_file (or --all-wells)")
+    if args.layout == "interleaved" and (args.all_wells or (args.edit_distance > 3 and not args.hamming)):
+        p.error("--layout interleaved needs sampled targets (-f) and, for the edit distance, -e <= 3")
     return args
 
 
@@ -130,7 +137,7 @@ class _Loading:
 
 
 def scan_lane(sc: Scanner, reader, lane, tiles, cycle_list, mode, k, csr, wells, tile_batch,
-              threads, want_log, overlap=True):
+              threads, want_log, overlap=True, interleave=1):
     """The given tiles of one lane -> ({tile: TileCounts}, {tile: [log lines]}).
 
     Double-buffered: while the GPU scans batch n (and its report rows and log lines are put
@@ -157,7 +164,7 @@ def scan_lane(sc: Scanner, reader, lane, tiles, cycle_list, mode, k, csr, wells,
         if wells.size and (wells[-1] >= n_clusters or wells[0] < 0):
             raise IndexError("Requested cluster %i is out of range.  Highest on this "
                              "tile is %i." % (int(wells[-1]), n_clusters - 1))
-        tb = TileBatch(sc, len(chunk), len(cycle_list), n_clusters)
+        tb = TileBatch(sc, len(chunk), len(cycle_list), n_clusters, interleave=interleave)
         live.append(tb)
         # ingest: every (tile, cycle) file is gunzipped into pinned memory and copied to the GPU
         # by libwelldup (wd_load_bcl_gz).  Runs without .bcl.gz files are NovaSeq runs: the
@@ -168,8 +175,10 @@ def scan_lane(sc: Scanner, reader, lane, tiles, cycle_list, mode, k, csr, wells,
 
         def load(i, c):
             try:
-                sc.load_bcl_gz(handles[i].plane_path(cycle_list[c]), tb.plane_ptr(i, c), n_clusters)
+                sc.load_bcl_gz(handles[i].plane_path(cycle_list[c]), tb.plane_ptr(i, c), n_clusters, interleave)
             except FileNotFoundError:       # only a missing file: a corrupt one is reported as such
+                if interleave != 1:
+                    raise RuntimeError("--layout interleaved reads .bcl.gz runs only") from None
                 filt[i].result()
                 sc.load_cbcl_tile(handles[i].cbcl_path(cycle_list[c]), int(handles[i].tile),
                                   tb.filter_ptr(i), n_clusters, tb.plane_ptr(i, c))
@@ -193,8 +202,7 @@ def scan_lane(sc: Scanner, reader, lane, tiles, cycle_list, mode, k, csr, wells,
             for i in range(len(chunk)):
                 if want_log and wells.size:
                     # only the bytes of wells some target touches come back, for the stderr log
-                    seq_bytes[i] = sc.gather_wells([tb.plane_ptr(i, c) for c in range(len(cycle_list))],
-                                                   wells, n_clusters)
+                    seq_bytes[i] = sc.gather_wells_batch(tb, i, wells)
             if want_log:
                 sc.hitlog_enable(max(1024, int(nbr.size) * len(chunk)))
             blocks, _ = tb.count(mode, k)
@@ -304,7 +312,8 @@ def main(argv=None):
                     counts, lane_logs = scan_lane(sc, reader, lane, lane_tiles, cycle_list, mode, k, csr, wells,
                                                   max(1, args.tile_batch), args.threads,
                                                   0 if (args.quiet or args.all_wells) else len(cycles),
-                                                  overlap=not args.serial_ingest)
+                                                  overlap=not args.serial_ingest,
+                                                  interleave=4 if args.layout == "interleaved" else 1)
                     for i, (ln, t) in enumerate(mine):
                         if ln == lane:
                             c = counts[t]

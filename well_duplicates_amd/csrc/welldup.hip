@@ -456,6 +456,12 @@ template <bool STRIDED, int H>
 void launch_queue_lev(wd_ctx *ctx, const ScanArgs &a, dim3 grid)
 {
     const size_t lds = (size_t)scan_q_lds_dwords(a.levels, a.tpb, 4) * sizeof(uint32_t);
+    if constexpr (STRIDED && H == 1) {
+        if (ctx->well_stride == 4) {                    // interleaved: the first round is two dwords per well
+            hipLaunchKernelGGL((k_scan_q<true, 8, 1, 4>), grid, dim3(kBlock), lds, ctx->stream, a);
+            return;
+        }
+    }
     // an odd threshold (k = 2H + 1) keeps random neighbours alive about one cycle longer
     if (a.k & 1)
         hipLaunchKernelGGL((k_scan_q<STRIDED, lev_first(H) + 1, H>), grid, dim3(kBlock), lds, ctx->stream, a);
@@ -1192,9 +1198,12 @@ int wd_scan_async(wd_ctx *ctx, int n_tiles, int L, int mode, int k, const uint8_
 
     const bool use_queue = !lev && ctx->queue_kernel && ctx->early_exit && kk <= 254 &&
                            ctx->k_max <= (int64_t)kMaxPasses * kPass;
-    if (ws == 4 && (use_dense || !use_queue || !strided))
+    // Levenshtein <= 2 / <= 3 in the queue kernel (band half-width 1) reads the interleaved layout too
+    const bool lev_queue_il = lev && !lev_generic && kk / 2 == 1 && ctx->queue_kernel && ctx->early_exit &&
+                              ctx->k_max <= (int64_t)kMaxPasses * kPass;
+    if (ws == 4 && (use_dense || !strided || !(use_queue || lev_queue_il)))
         return fail(ctx, WD_ERR_UNSUPPORTED,
-                    "the interleaved layout is read by the equality / Hamming queue kernel only");
+                    "the interleaved layout is read by the queue kernel only (equality, Hamming, Levenshtein <= 3)");
 
     std::pair<hipEvent_t, hipEvent_t> ev{nullptr, nullptr};
     const bool timed = ctx->profile > 0 && (ctx->profile_seq++ % ctx->profile) == 0;
@@ -1732,7 +1741,12 @@ int wd_gunzip(const uint8_t *src, size_t src_len, uint8_t *dst, size_t dst_cap, 
 // its own pinned buffer and copy stream); they do not touch the context's error string.
 int wd_load_bcl_gz(wd_ctx *ctx, const char *path, uint8_t *dst_dev, int64_t n_clusters)
 {
-    if (!ctx || !path || !dst_dev || n_clusters < 0)
+    return wd_load_bcl_gz_strided(ctx, path, dst_dev, n_clusters, 1);
+}
+
+int wd_load_bcl_gz_strided(wd_ctx *ctx, const char *path, uint8_t *dst_dev, int64_t n_clusters, int well_stride)
+{
+    if (!ctx || !path || !dst_dev || n_clusters < 0 || (well_stride != 1 && well_stride != 4))
         return WD_ERR_ARG;
     if (hipSetDevice(ctx->device) != hipSuccess)
         return WD_ERR_HIP;
@@ -1795,10 +1809,29 @@ int wd_load_bcl_gz(wd_ctx *ctx, const char *path, uint8_t *dst_dev, int64_t n_cl
         return WD_ERR_FORMAT;
     if (produced < want)
         return WD_ERR_INDEX;                               // the reference fails at slurped_file[idx]
-    if (n_clusters > 0) {
+    if (n_clusters > 0 && well_stride == 1) {
         if (hipMemcpyAsync(dst_dev, lease.slot->pinned + 4, (size_t)n_clusters, hipMemcpyHostToDevice,
                            lease.slot->stream) != hipSuccess ||
             hipStreamSynchronize(lease.slot->stream) != hipSuccess)
+            return WD_ERR_HIP;
+    } else if (n_clusters > 0) {
+        // interleaved layout: the plane lands in the slot's device scratch and is scattered into its
+        // byte lane of the group of four cycles (same stream, so the order is given)
+        const size_t need = ((size_t)n_clusters + 255) & ~(size_t)255;
+        if (need > lease.slot->dev_cap) {
+            (void)hipFree(lease.slot->dev);
+            lease.slot->dev = nullptr;
+            lease.slot->dev_cap = 0;
+            if (hipMalloc((void **)&lease.slot->dev, need) != hipSuccess)
+                return WD_ERR_NOMEM;
+            lease.slot->dev_cap = need;
+        }
+        if (hipMemcpyAsync(lease.slot->dev, lease.slot->pinned + 4, (size_t)n_clusters, hipMemcpyHostToDevice,
+                           lease.slot->stream) != hipSuccess)
+            return WD_ERR_HIP;
+        hipLaunchKernelGGL(k_scatter_plane4, dim3((unsigned)((n_clusters + 4ll * kBlock - 1) / (4ll * kBlock))), dim3(kBlock),
+                           0, lease.slot->stream, lease.slot->dev, (long long)n_clusters, dst_dev);
+        if (hipGetLastError() != hipSuccess || hipStreamSynchronize(lease.slot->stream) != hipSuccess)
             return WD_ERR_HIP;
     }
     return WD_OK;
@@ -1969,7 +2002,7 @@ int wd_gather_wells(wd_ctx *ctx, const uint8_t *const *planes, int L, const int3
         return done(WD_ERR_HIP, "gather upload");
     const long long total = (long long)n * L;
     hipLaunchKernelGGL(k_gather_wells, dim3((unsigned)((total + kBlock - 1) / kBlock)), dim3(kBlock), 0,
-                       ctx->stream, d_pl, L, d_idx, (long long)n, d_out);
+                       ctx->stream, d_pl, L, d_idx, (long long)n, d_out, ctx->well_stride);
     if (hipGetLastError() != hipSuccess ||
         hipMemcpyAsync(out_host, d_out, (size_t)total, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
         hipStreamSynchronize(ctx->stream) != hipSuccess)

@@ -235,9 +235,11 @@ class Scanner:
         self._ck(self._lib.wd_scan_status(self._ctx))
 
     # ------------------------------------------------------------------ ingest
-    def load_bcl_gz(self, path: str, dst: int, n_clusters: int):
-        """gunzip a .bcl.gz straight into device memory (thread-safe, releases the GIL)."""
-        rc = self._lib.wd_load_bcl_gz(self._ctx, os.fsencode(path), ctypes.c_void_p(dst), int(n_clusters))
+    def load_bcl_gz(self, path: str, dst: int, n_clusters: int, well_stride: int = 1):
+        """gunzip a .bcl.gz straight into device memory (thread-safe, releases the GIL);
+        well_stride = 4 writes the plane into its byte lane of an interleaved group."""
+        rc = self._lib.wd_load_bcl_gz_strided(self._ctx, os.fsencode(path), ctypes.c_void_p(dst), int(n_clusters),
+                                              int(well_stride))
         if rc != _lib.OK:
             _raise(self._lib, None, rc, path)
 
@@ -263,6 +265,14 @@ class Scanner:
                                            idx.shape[0], int(n_clusters),
                                            out.ctypes.data_as(ctypes.c_void_p)))
         return out
+
+    def gather_wells_batch(self, tb: "TileBatch", tile: int, idx) -> np.ndarray:
+        """gather_wells over every cycle of one tile of a TileBatch, in the batch's layout."""
+        self.set_option("well_stride", tb.interleave)
+        try:
+            return self.gather_wells([tb.plane_ptr(tile, c) for c in range(tb.L)], idx, tb.N)
+        finally:
+            self.set_option("well_stride", 1)
 
     # ------------------------------------------------------------------ dup log / profile
     def hitlog_enable(self, capacity: int):
