@@ -72,7 +72,7 @@ def parse():
     ap.add_argument("--profile-steps", type=int, default=20)
     ap.add_argument("--interleaved-tiles", type=int, default=96,
                     help="tiles of the interleaved-layout measurement under other_modes; 0 = skip")
-    ap.add_argument("--e2e-tiles", type=int, default=4,
+    ap.add_argument("--e2e-tiles", type=int, default=16,
                     help="full-size tiles of the end-to-end (real files) measurement; 0 = skip")
     ap.add_argument("--novaseq-tiles", type=int, default=96,
                     help="tiles of the BASELINE configs[3] shape (NovaSeq tiles, 10000 targets x 7 levels) reported "
@@ -267,6 +267,8 @@ def e2e_probe(device, n_tiles, rows, cols, centre, lvl_off, nbr, cycles=50, thre
         run([])                                               # page cache, allocator, first-use costs
         best, text = min(run([]) for _ in range(2))
         serial, text_s = min(run(["--serial-ingest"]) for _ in range(2))
+        run(["--host-inflate"])
+        host, text_h = min(run(["--host-inflate"]) for _ in range(2))
         inter, text_i = min(run(["--layout", "interleaved"]) for _ in range(2))
         plane_bytes = n_tiles * cycles * n
         return {"what": "count_well_duplicates CLI (-e 2 Levenshtein, %d targets x %d levels, -q -S) on %d full-size "
@@ -277,8 +279,12 @@ def e2e_probe(device, n_tiles, rows, cols, centre, lvl_off, nbr, cycles=50, thre
                 "plane_gb_per_s": round(plane_bytes / best / 1e9, 3),
                 "serial_ingest_seconds": round(serial, 4),
                 "overlap_gain": round(serial / best, 3) if best > 0 else None,
+                "inflate": "GPU (one wave per .bcl.gz file, csrc/gpu_inflate.inc); host threads only read the files",
+                "host_inflate_seconds": round(host, 4),
+                "gpu_inflate_gain": round(host / best, 3) if best > 0 else None,
                 "interleaved_layout_seconds": round(inter, 4),
-                "same_report": text == text_s == text_i, "run_dir_write_s": round(write_s, 1),
+                "interleaved_layout_note": "host inflate (the GPU decoder writes plain planes)",
+                "same_report": text == text_s == text_i == text_h, "run_dir_write_s": round(write_s, 1),
                 "reference_s_per_tile": 7.9,
                 "reference_note": "unmodified reference, 1 core, same geometry, --hamming -e 0 (BASELINE.md; measured in "
                                   "the build container, not on this box)"}

@@ -204,6 +204,21 @@ int wd_load_bcl_gz(wd_ctx *ctx, const char *path, uint8_t *dst_dev, int64_t n_cl
  * cycle inside its group of four (group base + cycle % 4), well_stride = 4; 1 = wd_load_bcl_gz. */
 int wd_load_bcl_gz_strided(wd_ctx *ctx, const char *path, uint8_t *dst_dev, int64_t n_clusters, int well_stride);
 int wd_load_filter(wd_ctx *ctx, const char *path, uint8_t *dst_dev, int64_t n_clusters);
+/* A batch of .bcl.gz files (typically all cycles of a few tiles) decoded ON THE GPU: the same
+ * contract as n_files calls of wd_load_bcl_gz (bcl_direct_reader.py:200-216, :333-345), file i ->
+ * dst_dev[i] (4-byte aligned, n_clusters bytes).  `threads` host threads only read the compressed
+ * files into pinned memory; the compressed bytes cross PCIe, one wave per file inflates them
+ * (csrc/gpu_inflate.inc: the 64 lanes decode 64 pieces of a block's bit stream at once), a second
+ * kernel takes the CRC-32 and the gzip trailer (CRC, length), the cluster count and the plane size
+ * are checked.  The GPU decoder is an accelerator, not an authority: a file it declines or whose
+ * checks fail (corrupt, truncated, several members, header options, a piece of the stream that
+ * expands more than 256-fold) is loaded again by wd_load_bcl_gz, whose return code is the one
+ * reported.  rc (nullable): n_files WD_* codes; the return value is the first non-zero one.
+ * One batch at a time per context (calls are serialised); safe beside the other loaders.
+ * wd_get_option "inflate_files_gpu" / "inflate_files_host" count how the files of all batches were
+ * decoded; option "inflate_chunk_mb" (default 16) sizes the 4 pinned staging chunks. */
+int wd_load_bcl_gz_batch(wd_ctx *ctx, int n_files, const char *const *paths, uint8_t *const *dst_dev,
+                         int64_t n_clusters, int threads, int *rc);
 /* Resident layout option for the equality / Hamming scan of sampled targets.  A line of HBM holds
  * 128 wells of ONE cycle in the BCL files' plane-per-cycle layout, and the scan wants ~11
  * neighbouring wells of SEVERAL cycles: with the cycles interleaved by four ([group of 4 cycles]

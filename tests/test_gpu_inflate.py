@@ -1,0 +1,217 @@
+"""GPU DEFLATE decoder (csrc/gpu_inflate.inc, wd_load_bcl_gz_batch) against Python's gzip module -
+the reference's own decompressor (bcl_direct_reader.py:208-209: gzip.open(...).read())."""
+import gzip
+import os
+import zlib
+
+import numpy as np
+import pytest
+
+from well_duplicates_amd import synth
+from well_duplicates_amd.scanner import Scanner
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def sc():
+    s = Scanner(0)
+    yield s
+    s.close()
+
+
+def _bcl(payload: np.ndarray, level: int = 6, **kw) -> bytes:
+    return gzip.compress(synth.bcl_file_bytes(payload), compresslevel=level, **kw)
+
+
+def _planes(n, kinds):
+    """Payloads that stress different parts of the decoder."""
+    rng = np.random.default_rng(42)
+    out = {}
+    for kind in kinds:
+        if kind.startswith("q"):                        # base calls with that many quality values
+            spec = synth.SynthSpec(seed=9, n_clusters=n, row=1000, qual_levels=int(kind[1:]), nocall_per_64k=2000)
+            out[kind] = synth.plane_bytes(spec, 1, 1101, 7)
+        elif kind == "noise":                           # incompressible: stored blocks
+            out[kind] = rng.integers(0, 256, n, dtype=np.uint8)
+        elif kind == "runs":                            # long matches, short distances, overlapping copies
+            v = rng.integers(0, 4, n // 50 + 1, dtype=np.uint8).repeat(50)[:n] * 7 + 8
+            out[kind] = v.astype(np.uint8)
+        elif kind == "zeros":                           # a failed cycle: every well a no-call (the decoder declines, zlib decodes)
+            out[kind] = np.zeros(n, np.uint8)
+        elif kind == "period":                          # far matches with long lengths
+            base = rng.integers(1, 255, 9000, dtype=np.uint8)
+            out[kind] = np.tile(base, n // 9000 + 1)[:n]
+        elif kind == "skew":                            # very uneven symbol frequencies: long and short codes
+            p = 0.5 ** np.arange(1, 25)
+            out[kind] = rng.choice(24, size=n, p=p / p.sum()).astype(np.uint8) + 1
+        else:
+            raise KeyError(kind)
+    return out
+
+
+def _load_and_check(sc, tmp_path, files, n, threads=4):
+    """files: {name: (bytes on disk, expected payload or exception class)}"""
+    names = list(files)
+    paths = []
+    for name in names:
+        p = tmp_path / (name + ".bcl.gz")
+        p.write_bytes(files[name][0])
+        paths.append(str(p))
+    stride = (n + 255) // 256 * 256
+    buf = sc.malloc(stride * len(names) + 256)
+    sc.memset(buf, 0xEE, stride * len(names) + 256)
+    dsts = [buf + i * stride for i in range(len(names))]
+    g0, h0 = sc.get_option("inflate_files_gpu"), sc.get_option("inflate_files_host")
+    good = [i for i, nm in enumerate(names) if isinstance(files[nm][1], np.ndarray)]
+    sc.load_bcl_gz_batch([paths[i] for i in good], [dsts[i] for i in good], n, threads=threads)
+    for i in good:
+        got = sc.d2h(dsts[i], n)
+        assert (got == files[names[i]][1]).all(), names[i]
+        if n < stride:                                  # nothing written past the plane
+            assert (sc.d2h(dsts[i] + n, stride - n) == 0xEE).all(), names[i]
+    for i, nm in enumerate(names):
+        if i in good:
+            continue
+        with pytest.raises(files[nm][1], match=nm):
+            sc.load_bcl_gz_batch([paths[i]], [dsts[i]], n, threads=1)
+    by_gpu = sc.get_option("inflate_files_gpu") - g0
+    by_host = sc.get_option("inflate_files_host") - h0
+    sc.free(buf)
+    return by_gpu, by_host
+
+
+def test_batch_matches_gzip_module(sc, tmp_path):
+    n = 400003
+    pl = _planes(n, ["q7", "q39", "q2", "noise", "runs", "period", "skew", "zeros"])
+    files = {}
+    for kind, payload in pl.items():
+        for level in (1, 6, 9):
+            files["%s_l%d" % (kind, level)] = (_bcl(payload, level), payload)
+    # fixed Huffman codes only (Z_FIXED), and a stream with sync-flush points (empty stored blocks)
+    co = zlib.compressobj(6, zlib.DEFLATED, 31, 8, zlib.Z_FIXED)
+    raw = synth.bcl_file_bytes(pl["q7"])
+    files["fixed"] = (co.compress(raw) + co.flush(), pl["q7"])
+    co = zlib.compressobj(6, zlib.DEFLATED, 31)
+    parts = [co.compress(raw[i:i + 50000]) + co.flush(zlib.Z_SYNC_FLUSH) for i in range(0, len(raw), 50000)]
+    files["flushes"] = (b"".join(parts) + co.flush(), pl["q7"])
+    # a file name in the gzip header (FNAME), as `gzip file` writes it
+    files["named"] = (gzip.compress(raw, 6)[:3] + b"\x08" + gzip.compress(raw, 6)[4:10] + b"s_1_1101.bcl\0"
+                      + gzip.compress(raw, 6)[10:], pl["q7"])
+    by_gpu, by_host = _load_and_check(sc, tmp_path, files, n)
+    # the decoder took everything but (some of) the all-zero planes, where one piece of the stream
+    # expands more than a window holds
+    assert by_gpu + by_host == len(files) and by_host <= 3, (by_gpu, by_host)
+
+
+def test_batch_decoded_on_the_gpu_at_full_size(sc, tmp_path):
+    """A full-size plane (4.3 M wells), more files than one staging chunk holds."""
+    n = 4309253
+    sc.set_option("inflate_chunk_mb", 8)
+    try:
+        files = {}
+        for c, q in enumerate((7, 7, 39, 7, 2, 7, 7)):
+            spec = synth.SynthSpec(seed=21, n_clusters=n, row=1571, qual_levels=q)
+            payload = synth.plane_bytes(spec, 2, 1205, c)
+            files["c%d" % c] = (_bcl(payload, 6 if c % 2 else 1), payload)
+        by_gpu, by_host = _load_and_check(sc, tmp_path, files, n, threads=3)
+        assert (by_gpu, by_host) == (len(files), 0)
+    finally:
+        sc.set_option("inflate_chunk_mb", 16)
+
+
+def test_batch_reports_what_the_reference_raises(sc, tmp_path):
+    n = 100001
+    spec = synth.SynthSpec(seed=5, n_clusters=n, row=333, qual_levels=7)
+    payload = synth.plane_bytes(spec, 1, 1101, 0)
+    raw = synth.bcl_file_bytes(payload)
+    whole = gzip.compress(raw, 6)
+    dmg = bytearray(whole)
+    for pos in range(len(dmg) // 2, len(dmg) // 2 + 64):
+        dmg[pos] ^= 0xFF
+    crc = bytearray(whole)
+    crc[-6] ^= 1                                        # CRC-32 in the trailer
+    flip = bytearray(whole)
+    flip[len(flip) // 3] ^= 4                           # one bit: often still a valid stream, caught by the CRC
+    files = {
+        "fine": (whole, payload),
+        "multi": (gzip.compress(raw[:1000]) + gzip.compress(raw[1000:60000]) + gzip.compress(raw[60000:]), payload),
+        "junk": (b"hello world" * 10, gzip.BadGzipFile),
+        "cut": (whole[:len(whole) // 2], EOFError),
+        "notrailer": (whole[:-8], EOFError),
+        "damaged": (bytes(dmg), (zlib.error, gzip.BadGzipFile)),
+        "badcrc": (bytes(crc), (zlib.error, gzip.BadGzipFile)),
+        "bitflip": (bytes(flip), (zlib.error, gzip.BadGzipFile, AssertionError, IndexError)),
+        "short": (gzip.compress(raw[:-10]), IndexError),                          # fails at slurped_file[idx] in the reference
+        "count": (gzip.compress(synth.bcl_file_bytes(payload[:-1]) + b"\0"), AssertionError),   # header != clusters (:338)
+        "long": (gzip.compress(raw + b"\1" * 100), payload),                        # extra bytes after the plane are never indexed
+    }
+    # every one of these must agree with what Python's gzip says about the same bytes
+    for name, (data, want) in files.items():
+        if isinstance(want, np.ndarray):
+            assert gzip.decompress(data)[4:4 + n] == want.tobytes(), name
+        elif want in (EOFError, gzip.BadGzipFile) or name in ("damaged", "badcrc"):
+            with pytest.raises((EOFError, gzip.BadGzipFile, zlib.error)):
+                gzip.decompress(data)
+    _load_and_check(sc, tmp_path, files, n)
+    # a missing file among good ones: reported per file
+    p = tmp_path / "fine.bcl.gz"
+    buf = sc.malloc(2 * n + 512)
+    missing = sc.load_bcl_gz_batch([str(p), str(tmp_path / "nope.bcl.gz")], [buf, buf + (n + 255) // 256 * 256], n,
+                                   threads=2, missing_ok=True)
+    assert missing == [1]
+    with pytest.raises(FileNotFoundError, match="nope"):
+        sc.load_bcl_gz_batch([str(p), str(tmp_path / "nope.bcl.gz")], [buf, buf + (n + 255) // 256 * 256], n)
+    sc.load_bcl_gz_batch([], [], n)
+    sc.free(buf)
+
+
+def test_corrupted_streams_end_with_a_verdict(sc, tmp_path):
+    """Random damage: the kernel must come back (no hang, no write outside the plane) and the loader's
+    answer must be the host decoder's: the same plane or an exception."""
+    n = 60001
+    spec = synth.SynthSpec(seed=8, n_clusters=n, row=250, qual_levels=7)
+    payload = synth.plane_bytes(spec, 1, 1101, 1)
+    whole = gzip.compress(synth.bcl_file_bytes(payload), 6)
+    rng = np.random.default_rng(7)
+    stride = (n + 255) // 256 * 256
+    cases = 96
+    buf = sc.malloc(stride * cases + 256)
+    sc.memset(buf, 0xEE, stride * cases + 256)
+    paths, datas = [], []
+    for i in range(cases):
+        m = bytearray(whole)
+        kind = i % 4
+        if kind == 0:
+            for _ in range(int(rng.integers(1, 4))):
+                m[int(rng.integers(10, len(m)))] ^= 1 << int(rng.integers(0, 8))
+        elif kind == 1:
+            m = m[:int(rng.integers(1, len(m)))]
+        elif kind == 2:
+            at = int(rng.integers(10, len(m)))
+            m[at:at + 32] = bytes(rng.integers(0, 256, min(32, len(m) - at), dtype=np.uint8))
+        else:
+            m[10 + int(rng.integers(0, 40))] ^= 1 << int(rng.integers(0, 8))
+        p = tmp_path / ("case%03d.bcl.gz" % i)
+        p.write_bytes(bytes(m))
+        paths.append(str(p))
+        datas.append(bytes(m))
+    rcs_ok = 0
+    for i in range(cases):                              # one at a time: each case gets its own verdict
+        try:
+            sc.load_bcl_gz_batch([paths[i]], [buf + i * stride], n, threads=1)
+            ok = True
+        except (EOFError, zlib.error, gzip.BadGzipFile, AssertionError, IndexError):
+            ok = False
+        try:
+            ref = gzip.decompress(datas[i])
+            ref_ok = len(ref) >= n + 4 and int.from_bytes(ref[:4], "little") == n
+        except (EOFError, zlib.error, gzip.BadGzipFile):
+            ref, ref_ok = None, False
+        assert ok == ref_ok, (i, ok, ref_ok)
+        if ok:
+            rcs_ok += 1
+            assert sc.d2h(buf + i * stride, n).tobytes() == ref[4:4 + n]
+        if n < stride:
+            assert (sc.d2h(buf + i * stride + n, stride - n) == 0xEE).all(), i
+    sc.free(buf)

@@ -106,6 +106,10 @@ def parse_args(argv=None):
                         ".bcl.gz files; interleaved = the four cycles of a group side by side per well (the "
                         "loaders write it at no extra cost; the scan of sampled targets then touches half the "
                         "cache lines).  interleaved: .bcl.gz runs, -e <= 3, not with --all-wells")
+    p.add_argument("--host-inflate", action="store_true",
+                   help="gunzip the .bcl.gz files on the host threads (the default inflates them on the GPU: "
+                        "the threads only read the compressed files, one wave per file decodes it; files the "
+                        "GPU decoder declines are gunzipped on the host either way)")
     p.add_argument("--serial-ingest", action="store_true",
                    help="load a batch of tiles only after the previous one has been scanned (for measuring "
                         "what the double-buffered ingest gains)")
@@ -117,6 +121,18 @@ def parse_args(argv=None):
     if args.layout == "interleaved" and (args.all_wells or (args.edit_distance > 3 and not args.hamming)):
         p.error("--layout interleaved needs sampled targets (-f) and, for the edit distance, -e <= 3")
     return args
+
+
+_T0 = [0.0]
+
+
+def _lap(what: str):
+    """WD_CLI_TIMING=1: where the wall clock of a run goes (stderr)."""
+    if os.environ.get("WD_CLI_TIMING"):
+        import time
+        now = time.perf_counter()
+        print("[wd timing] %-28s %7.1f ms" % (what, (now - _T0[0]) * 1e3), file=sys.stderr)
+        _T0[0] = now
 
 
 def _decode(seq_bytes: np.ndarray) -> str:
@@ -137,7 +153,7 @@ class _Loading:
 
 
 def scan_lane(sc: Scanner, reader, lane, tiles, cycle_list, mode, k, csr, wells, tile_batch,
-              threads, want_log, overlap=True, interleave=1):
+              threads, want_log, overlap=True, interleave=1, gpu_inflate=True):
     """The given tiles of one lane -> ({tile: TileCounts}, {tile: [log lines]}).
 
     Double-buffered: while the GPU scans batch n (and its report rows and log lines are put
@@ -182,7 +198,19 @@ def scan_lane(sc: Scanner, reader, lane, tiles, cycle_list, mode, k, csr, wells,
                 filt[i].result()
                 sc.load_cbcl_tile(handles[i].cbcl_path(cycle_list[c]), int(handles[i].tile),
                                   tb.filter_ptr(i), n_clusters, tb.plane_ptr(i, c))
-        planes = [pool.submit(load, i, c) for i in range(len(handles)) for c in range(len(cycle_list))]
+        jobs = [(i, c) for i in range(len(handles)) for c in range(len(cycle_list))]
+        if gpu_inflate and interleave == 1 and jobs and os.path.exists(handles[0].plane_path(cycle_list[0])):
+            # .bcl.gz run, plane layout: the whole batch goes through the GPU decoder
+            # (wd_load_bcl_gz_batch); its reader threads are the library's own
+            def load_all():
+                missing = sc.load_bcl_gz_batch([handles[i].plane_path(cycle_list[c]) for i, c in jobs],
+                                               [tb.plane_ptr(i, c) for i, c in jobs], n_clusters,
+                                               threads=max(1, threads), missing_ok=True)
+                for j in missing:           # (a run is .bcl.gz or .cbcl, never both: this loop is for the odd file)
+                    load(*jobs[j])
+            planes = [pool.submit(load_all)]
+        else:
+            planes = [pool.submit(load, i, c) for i, c in jobs]
         return _Loading(chunk, handles, tb, filt + planes)
 
     def release(tb):
@@ -190,12 +218,16 @@ def scan_lane(sc: Scanner, reader, lane, tiles, cycle_list, mode, k, csr, wells,
         tb.free()
 
     try:
-        nxt = start(batches[0]) if batches else None
+        # two batches on their way at any time: the second one's files are read and copied while the
+        # first one's are still being inflated (the GPU decoder's time per batch does not shrink
+        # with the batch), and both while the one before is scanned and reported
+        ahead = []
+        for b in batches[:2 if overlap else 1]:
+            ahead.append(start(b))
         for bi in range(len(batches)):
-            cur, nxt = nxt, None
+            cur = ahead.pop(0)
             cur.wait()
-            if overlap and bi + 1 < len(batches):
-                nxt = start(batches[bi + 1])           # loads while this batch is scanned
+            _lap("batch %d: planes in HBM" % bi)
             chunk, tb = cur.chunk, cur.tb
             n_clusters = tb.N
             seq_bytes = {}
@@ -206,6 +238,7 @@ def scan_lane(sc: Scanner, reader, lane, tiles, cycle_list, mode, k, csr, wells,
             if want_log:
                 sc.hitlog_enable(max(1024, int(nbr.size) * len(chunk)))
             blocks, _ = tb.count(mode, k)
+            _lap("batch %d: scanned" % bi)
             hits = None
             if want_log:
                 hits, total = sc.hitlog_fetch(max(1024, int(nbr.size) * len(chunk)))
@@ -213,6 +246,8 @@ def scan_lane(sc: Scanner, reader, lane, tiles, cycle_list, mode, k, csr, wells,
                 order = np.lexsort((hits["slot"], hits["target"], hits["tile"]))
                 hits = hits[order]
             release(tb)
+            if overlap and bi + 2 < len(batches):
+                ahead.append(start(batches[bi + 2]))
             for i, t in enumerate(chunk):
                 counts[t] = report.TileCounts.from_block(blocks[i], levels)
                 if want_log:
@@ -230,7 +265,7 @@ def scan_lane(sc: Scanner, reader, lane, tiles, cycle_list, mode, k, csr, wells,
                         lines.append("edit distance: {}".format(int(h["dist"])))
                     logs[t] = lines
             if not overlap and bi + 1 < len(batches):
-                nxt = start(batches[bi + 1])
+                ahead.append(start(batches[bi + 1]))
     finally:
         # queued loads are dropped, running ones finish - only then may their targets go
         pool.shutdown(wait=True, cancel_futures=True)
@@ -240,6 +275,9 @@ def scan_lane(sc: Scanner, reader, lane, tiles, cycle_list, mode, k, csr, wells,
 
 
 def main(argv=None):
+    if os.environ.get("WD_CLI_TIMING"):
+        import time
+        _T0[0] = time.perf_counter()
     args = parse_args(argv)
     log = (lambda msg: None) if args.quiet else (lambda msg: print(str(msg), file=sys.stderr))
 
@@ -259,8 +297,10 @@ def main(argv=None):
     else:
         targets = load_targets(filename=args.coord_file, levels=args.level + 1, limit=args.sample_size)
         csr = targets.to_csr(args.level)
-        wells = np.unique(np.asarray(targets.get_all_indices(), dtype=np.int64))
+        # every well some target touches = targets.get_all_indices(), sorted (the rings loaded are 1..-l)
+        wells = np.unique(np.concatenate([csr[0], csr[2]]).astype(np.int64))
     reader = bcl_direct_reader.BCLReader(args.run)
+    _lap("targets file, run directory")
 
     from . import dist as wdist
     rank, world, local_rank = wdist.env_rank()
@@ -285,6 +325,7 @@ def main(argv=None):
             else:
                 n_targets = len(targets)
                 sc.set_targets(*csr)
+            _lap("context, targets on the GPU")
             # (lane, tile) items are independent (count_well_duplicates.py:207-226): the flat list
             # is block-partitioned over the ranks, every rank scans its share lane by lane, and ONE
             # all-reduce of the [items, 1 + 5 levels] counter block (plus one gather of the log
@@ -313,7 +354,8 @@ def main(argv=None):
                                                   max(1, args.tile_batch), args.threads,
                                                   0 if (args.quiet or args.all_wells) else len(cycles),
                                                   overlap=not args.serial_ingest,
-                                                  interleave=4 if args.layout == "interleaved" else 1)
+                                                  interleave=4 if args.layout == "interleaved" else 1,
+                                                  gpu_inflate=not args.host_inflate)
                     for i, (ln, t) in enumerate(mine):
                         if ln == lane:
                             c = counts[t]
@@ -337,6 +379,7 @@ def main(argv=None):
             elif err is not None:
                 raise err
     finally:
+        _lap("reports, context closed")
         if out_fh:
             out_fh.close()
         if world > 1:

@@ -13,6 +13,7 @@
 //   scan_lev_generic.inc  Levenshtein with any threshold (DP row in LDS)
 //   gen_rings.inc         neighbour-index generator (prepare_cluster_indexes.py on device)
 //   ingest_kernels.inc    gather of a few wells' bytes for the duplicate log
+//   gpu_inflate.inc       DEFLATE on the GPU: one wave per .bcl.gz member (+ _kernels.inc: launch, CRC-32)
 //   welldup.hip           RCCL binding, context, C ABI
 //
 // Design in one paragraph (DESIGN.md has the full story): HBM-bound byte/integer work, no MFMA.
@@ -32,8 +33,16 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <fcntl.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
 #include <algorithm>
+#include <atomic>
+#include <condition_variable>
+#include <memory>
 #include <mutex>
+#include <thread>
 #include <type_traits>
 #include <string>
 #include <vector>
@@ -57,6 +66,8 @@ constexpr uint32_t kStatusEmptyLevel = 1u;
 #include "scan_lev_generic.inc"
 #include "gen_rings.inc"
 #include "ingest_kernels.inc"
+#include "gpu_inflate.inc"
+#include "gpu_inflate_kernels.inc"
 
 // -------------------------------------------------------------------------------------
 // RCCL, bound at run time
@@ -217,6 +228,43 @@ struct wd_ctx {
     };
     std::mutex ingest_mu;
     std::vector<IngestSlot *> ingest_slots;
+
+    // ingest through the GPU decoder (wd_load_bcl_gz_batch): the reader threads fill a ring of
+    // pinned chunks; each chunk's files are copied into the batch's arena in device memory and
+    // decoded by a launch of their own, on one of a pool of streams, while the next chunk is read
+    struct InflateChunk {
+        uint8_t *pinned = nullptr;
+        hipEvent_t copied = nullptr;                   // the chunk's H2D copy is done: it may be refilled
+    };
+    static constexpr int kInflateChunks = 4;
+    // The files are decoded in launches of kInflateLaunchFiles (what the chip holds at once: 3
+    // workgroups per CU) or whatever the batch has, all on ONE stream: a wave's time per file does not
+    // depend on how many files a launch holds, launches that share a hardware queue run one after the
+    // other anyway (HIP multiplexes its streams onto ~4 of them; 4 launches on 4 streams took 3 kernel
+    // times), and with a second stream for the chunk copies the next launch's files arrive while this
+    // one decodes.
+    static constexpr int kInflateStreams = 1;
+    static constexpr int kInflateLaunchFiles = 768;
+    size_t inflate_chunk_bytes = 16u << 20;            // option "inflate_chunk_mb" (pinning memory costs time: keep the ring small)
+    InflateChunk inflate_chunks[kInflateChunks];
+    size_t inflate_chunk_cap = 0;                      // bytes the chunks were allocated with
+    hipStream_t inflate_streams[kInflateStreams + 1] = {};
+    hipEvent_t inflate_ready[kInflateStreams] = {};    // a launch's files are all in the arena
+    // what a batch keeps until its last kernel is done; two, so that the next batch's files are read
+    // and copied while this batch's are still being decoded
+    struct InflateSlot {
+        std::mutex mu;
+        uint8_t *arena = nullptr;                      // compressed files of the batch (device)
+        size_t arena_cap = 0;
+        InfJob *h_jobs = nullptr, *d_jobs = nullptr;   // one entry per file of the batch
+        InfResult *h_res = nullptr, *d_res = nullptr;
+        size_t jobs_cap = 0;
+        hipEvent_t done = nullptr;                     // the batch's results are on the host
+    };
+    InflateSlot inflate_slots[2];
+    std::atomic<unsigned> inflate_calls{0};
+    std::mutex inflate_mu;                             // one batch at a time reads, copies and launches
+    std::atomic<long long> inflate_files_gpu{0}, inflate_files_host{0};   // how the files of all batches were decoded
 };
 
 namespace {
@@ -797,6 +845,28 @@ void wd_destroy(wd_ctx *ctx)
     (void)hipFree(ctx->d_out_pt);
     (void)hipFree(ctx->d_hits);
     (void)hipFree(ctx->d_hit_count);
+    for (auto &st : ctx->inflate_streams)
+        if (st) {
+            (void)hipStreamSynchronize(st);
+            (void)hipStreamDestroy(st);
+        }
+    for (auto &ev : ctx->inflate_ready)
+        if (ev)
+            (void)hipEventDestroy(ev);
+    for (auto &ch : ctx->inflate_chunks) {
+        (void)hipHostFree(ch.pinned);
+        if (ch.copied)
+            (void)hipEventDestroy(ch.copied);
+    }
+    for (auto &sl : ctx->inflate_slots) {
+        (void)hipFree(sl.arena);
+        (void)hipHostFree(sl.h_jobs);
+        (void)hipFree(sl.d_jobs);
+        (void)hipHostFree(sl.h_res);
+        (void)hipFree(sl.d_res);
+        if (sl.done)
+            (void)hipEventDestroy(sl.done);
+    }
     for (auto *sl : ctx->ingest_slots) {
         (void)hipHostFree(sl->pinned);
         (void)hipFree(sl->dev);
@@ -868,6 +938,10 @@ int wd_set_option(wd_ctx *ctx, const char *name, int64_t value)
         ctx->well_stride = (int)value;
     } else if (n == "fast_inflate") {
         ctx->fast_inflate = value ? 1 : 0;
+    } else if (n == "inflate_chunk_mb") {
+        if (value < 1 || value > 1024)
+            return WD_ERR_ARG;
+        ctx->inflate_chunk_bytes = (size_t)value << 20;
     } else if (n == "dense_pack") {
         ctx->dense_pack = value < 0 ? -1 : (value ? 1 : 0);
     } else if (n == "dense_windows") {
@@ -908,6 +982,9 @@ int wd_get_option(wd_ctx *ctx, const char *name, int64_t *value)
     else if (n == "dense_windows") *value = ctx->dense_windows;
     else if (n == "dense_nt") *value = ctx->dense_nt;
     else if (n == "fast_inflate") *value = ctx->fast_inflate;
+    else if (n == "inflate_chunk_mb") *value = (long long)(ctx->inflate_chunk_bytes >> 20);
+    else if (n == "inflate_files_gpu") *value = ctx->inflate_files_gpu.load();
+    else if (n == "inflate_files_host") *value = ctx->inflate_files_host.load();
     else if (n == "well_stride") *value = ctx->well_stride;
     else if (n == "null_stream") *value = ctx->stream == nullptr ? 1 : 0;
     else if (n == "queue_first") *value = ctx->queue_first;
@@ -1835,6 +1912,321 @@ int wd_load_bcl_gz_strided(wd_ctx *ctx, const char *path, uint8_t *dst_dev, int6
             return WD_ERR_HIP;
     }
     return WD_OK;
+}
+
+// ---- a batch of .bcl.gz files through the GPU decoder ------------------------------------------
+namespace {
+
+// buffers of a batch: pinned ring, streams, arena for `arena_bytes` of compressed files, n job slots
+int inflate_prepare(wd_ctx *ctx, wd_ctx::InflateSlot &sl, int n_chunks, size_t arena_bytes, size_t n_jobs)
+{
+    if (!sl.done && hipEventCreateWithFlags(&sl.done, hipEventDisableTiming) != hipSuccess)
+        return WD_ERR_HIP;
+    if (ctx->inflate_chunk_cap != ctx->inflate_chunk_bytes) {            // the option changed: new buffers
+        for (auto &ch : ctx->inflate_chunks) {
+            (void)hipHostFree(ch.pinned);
+            ch.pinned = nullptr;
+        }
+        ctx->inflate_chunk_cap = ctx->inflate_chunk_bytes;
+    }
+    for (int c = 0; c < n_chunks; c++) {
+        wd_ctx::InflateChunk &ch = ctx->inflate_chunks[c];
+        if (!ch.copied && hipEventCreateWithFlags(&ch.copied, hipEventDisableTiming) != hipSuccess)
+            return WD_ERR_HIP;
+        if (!ch.pinned && hipHostMalloc((void **)&ch.pinned, ctx->inflate_chunk_cap + 64, hipHostMallocDefault) != hipSuccess)
+            return WD_ERR_NOMEM;
+    }
+    for (auto &st : ctx->inflate_streams)
+        if (!st && hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess)
+            return WD_ERR_HIP;
+    for (auto &ev : ctx->inflate_ready)
+        if (!ev && hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess)
+            return WD_ERR_HIP;
+    if (arena_bytes > sl.arena_cap) {
+        (void)hipFree(sl.arena);
+        sl.arena = nullptr;
+        sl.arena_cap = 0;
+        const size_t want = arena_bytes + (arena_bytes >> 2) + 64;
+        if (hipMalloc((void **)&sl.arena, want) != hipSuccess)
+            return WD_ERR_NOMEM;
+        sl.arena_cap = want;
+    }
+    if (n_jobs > sl.jobs_cap) {
+        (void)hipHostFree(sl.h_jobs);
+        (void)hipFree(sl.d_jobs);
+        (void)hipHostFree(sl.h_res);
+        (void)hipFree(sl.d_res);
+        sl.h_jobs = sl.d_jobs = nullptr;
+        sl.h_res = sl.d_res = nullptr;
+        sl.jobs_cap = 0;
+        const size_t want = n_jobs + (n_jobs >> 1) + 64;
+        if (hipHostMalloc((void **)&sl.h_jobs, sizeof(InfJob) * want, hipHostMallocDefault) != hipSuccess ||
+            hipMalloc((void **)&sl.d_jobs, sizeof(InfJob) * want) != hipSuccess ||
+            hipHostMalloc((void **)&sl.h_res, sizeof(InfResult) * want, hipHostMallocDefault) != hipSuccess ||
+            hipMalloc((void **)&sl.d_res, sizeof(InfResult) * want) != hipSuccess)
+            return WD_ERR_NOMEM;
+        sl.jobs_cap = want;
+    }
+    return WD_OK;
+}
+
+}  // namespace
+
+int wd_load_bcl_gz_batch(wd_ctx *ctx, int n_files, const char *const *paths, uint8_t *const *dst_dev,
+                         int64_t n_clusters, int threads, int *rc_out)
+{
+    if (!ctx || n_files < 0 || (n_files && (!paths || !dst_dev)) || n_clusters < 0 || n_clusters > 0x7FFFFFF0ll)
+        return WD_ERR_ARG;
+    if (hipSetDevice(ctx->device) != hipSuccess)
+        return WD_ERR_HIP;
+    // a slot for the whole call, the shared ring / streams only while this batch is read and launched
+    wd_ctx::InflateSlot &slot = ctx->inflate_slots[ctx->inflate_calls.fetch_add(1) & 1];
+    std::lock_guard<std::mutex> slot_lock(slot.mu);
+    std::unique_lock<std::mutex> batch_lock(ctx->inflate_mu);
+    threads = std::max(1, std::min(threads, 256));
+    constexpr int kChunks = wd_ctx::kInflateChunks, kStreams = wd_ctx::kInflateStreams;
+    const size_t chunk_bytes = ctx->inflate_chunk_bytes;
+
+    enum : int { PENDING = 1, HOST = 2 };                                // beside the WD_* codes (<= 0)
+    std::vector<int> rc((size_t)n_files, PENDING);
+    std::vector<size_t> size((size_t)n_files, 0), offset((size_t)n_files, 0);   // offset: in the group's chunk
+    std::vector<uint32_t> stream_off((size_t)n_files, 0);
+    std::vector<uint64_t> trailer((size_t)n_files, 0);                   // CRC-32 | length << 32, as the file ends
+    std::vector<int> group_of((size_t)n_files, -1);
+    struct Group { int first, last; size_t bytes, arena_at; std::atomic<int> remaining{0}; };
+    std::vector<std::unique_ptr<Group>> groups;
+    size_t arena_bytes = 0, n_jobs = 0;
+    // sizes, then groups of consecutive files that fit a chunk
+    for (int i = 0; i < n_files; i++) {
+        struct stat st;
+        if (!paths[i] || !dst_dev[i] || ((uintptr_t)dst_dev[i] & 3)) {
+            rc[(size_t)i] = WD_ERR_ARG;
+        } else if (stat(paths[i], &st) != 0 || !S_ISREG(st.st_mode)) {
+            rc[(size_t)i] = WD_ERR_IO;                                   // FileNotFoundError in the reference
+        } else if ((size_t)st.st_size + 16 > chunk_bytes || st.st_size < 18 || (uint64_t)st.st_size > 0x1FFFFFF0ull) {
+            rc[(size_t)i] = HOST;
+        } else {
+            size[(size_t)i] = (size_t)st.st_size;
+            const size_t padded = (size[(size_t)i] + 15) & ~(size_t)15;
+            if (groups.empty() || groups.back()->bytes + padded > chunk_bytes)
+                groups.emplace_back(new Group{i, i, 0, arena_bytes});
+            Group &g = *groups.back();
+            offset[(size_t)i] = g.bytes;
+            g.bytes += padded;
+            arena_bytes += padded;
+            g.last = i;
+            g.remaining.fetch_add(1);
+            group_of[(size_t)i] = (int)groups.size() - 1;
+            n_jobs++;
+        }
+    }
+    const int n_groups = (int)groups.size();
+    if (n_groups) {
+        const int prc = inflate_prepare(ctx, slot, std::min(n_groups, kChunks), arena_bytes, n_jobs);
+        if (prc)
+            return prc;
+        // (the batch before may still be decoding; its chunk copies are behind us after this)
+        if (hipStreamSynchronize(ctx->inflate_streams[kStreams]) != hipSuccess)
+            return WD_ERR_HIP;
+    }
+
+    std::mutex mu;
+    std::condition_variable cv;
+    int free_upto = kChunks;                 // groups < free_upto may be filled
+    bool abort_all = false;
+    std::atomic<int> next_file{0};
+
+    auto reader = [&]() {
+        for (;;) {
+            const int i = next_file.fetch_add(1);
+            if (i >= n_files)
+                return;
+            const int g = group_of[(size_t)i];
+            if (g < 0)
+                continue;
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv.wait(lk, [&] { return abort_all || g < free_upto; });
+                if (abort_all)
+                    return;
+            }
+            uint8_t *dst = ctx->inflate_chunks[g % kChunks].pinned + offset[(size_t)i];
+            const size_t sz = size[(size_t)i];
+            bool ok = false;
+            const int fd = open(paths[i], O_RDONLY);
+            if (fd >= 0) {
+                size_t got = 0;
+                while (got < sz) {
+                    const ssize_t k = pread(fd, dst + got, sz - got, (off_t)got);
+                    if (k <= 0)
+                        break;
+                    got += (size_t)k;
+                }
+                ok = got == sz;
+                close(fd);
+            }
+            if (!ok || !inf_gzip_header(dst, sz, &stream_off[(size_t)i]))
+                rc[(size_t)i] = HOST;                                    // let the host path say what is wrong with it
+            else
+                memcpy(&trailer[(size_t)i], dst + sz - 8, 8);
+            if (groups[(size_t)g]->remaining.fetch_sub(1) == 1) {
+                std::lock_guard<std::mutex> lk(mu);
+                cv.notify_all();
+            }
+        }
+    };
+    std::vector<std::thread> pool;
+    for (int t = 0; t < threads && t < std::max(1, n_files); t++)
+        pool.emplace_back(reader);
+
+    // The chunks go to the arena one by one on the copy stream; a launch on the decode stream waits
+    // for the copy of its last chunk (see kInflateLaunchFiles).
+    std::vector<int> job_file;                                           // file index of every job, in launch order
+    job_file.reserve(n_jobs);
+    int hip_rc = WD_OK;
+    hipStream_t copy_stream = ctx->inflate_streams[kStreams];
+    int launch = 0;
+    size_t j0 = 0;                                                       // first job of the launch being gathered
+    for (int g = 0; g < n_groups && hip_rc == WD_OK; g++) {
+        Group &grp = *groups[(size_t)g];
+        {
+            std::unique_lock<std::mutex> lk(mu);
+            cv.wait(lk, [&] { return grp.remaining.load() == 0; });
+        }
+        wd_ctx::InflateChunk &ch = ctx->inflate_chunks[g % kChunks];
+        uint8_t *dev = slot.arena + grp.arena_at;
+        for (int i = grp.first; i <= grp.last; i++) {
+            if (group_of[(size_t)i] != g || rc[(size_t)i] != PENDING)
+                continue;
+            InfJob &j = slot.h_jobs[job_file.size()];
+            j.file = reinterpret_cast<const uint32_t *>(dev + offset[(size_t)i]);
+            j.obase = dst_dev[i] - 4;
+            j.file_bytes = (uint32_t)size[(size_t)i];
+            j.stream_off = stream_off[(size_t)i];
+            j.out_cap = (uint32_t)(n_clusters + 4);
+            j.pad_ = 0;
+            job_file.push_back(i);
+        }
+        if (hipMemcpyAsync(dev, ch.pinned, grp.bytes, hipMemcpyHostToDevice, copy_stream) != hipSuccess ||
+            hipEventRecord(ch.copied, copy_stream) != hipSuccess) {
+            hip_rc = WD_ERR_HIP;
+            break;
+        }
+        // enough files for a launch, or the last chunk: decode them
+        if (g + 1 == n_groups || job_file.size() - j0 >= (size_t)wd_ctx::kInflateLaunchFiles) {
+            const unsigned nj = (unsigned)(job_file.size() - j0);
+            hipStream_t stream = ctx->inflate_streams[0];
+            if (nj) {
+                if (hipEventRecord(ctx->inflate_ready[0], copy_stream) != hipSuccess ||
+                    hipStreamWaitEvent(stream, ctx->inflate_ready[0], 0) != hipSuccess ||
+                    hipMemcpyAsync(slot.d_jobs + j0, slot.h_jobs + j0, sizeof(InfJob) * nj,
+                                   hipMemcpyHostToDevice, stream) != hipSuccess) {
+                    hip_rc = WD_ERR_HIP;
+                    break;
+                }
+                hipLaunchKernelGGL(k_inflate, dim3(nj), dim3(64), 0, stream, slot.d_jobs + j0, slot.d_res + j0);
+                hipLaunchKernelGGL(k_inflate_crc, dim3(nj), dim3(256), 0, stream, slot.d_jobs + j0,
+                                   slot.d_res + j0);
+                if (hipGetLastError() != hipSuccess ||
+                    hipMemcpyAsync(slot.h_res + j0, slot.d_res + j0, sizeof(InfResult) * nj,
+                                   hipMemcpyDeviceToHost, stream) != hipSuccess) {
+                    hip_rc = WD_ERR_HIP;
+                    break;
+                }
+            }
+            j0 = job_file.size();
+            launch++;
+        }
+        if (g + 1 >= kChunks) {                                          // the chunk group g + 1 wants: is its copy done?
+            if (hipEventSynchronize(ctx->inflate_chunks[(g + 1) % kChunks].copied) != hipSuccess) {
+                hip_rc = WD_ERR_HIP;
+                break;
+            }
+            std::lock_guard<std::mutex> lk(mu);
+            free_upto = g + 2;
+            cv.notify_all();
+        }
+    }
+    if (hip_rc != WD_OK) {
+        std::lock_guard<std::mutex> lk(mu);
+        abort_all = true;
+        cv.notify_all();
+    }
+    for (auto &t : pool)
+        t.join();
+    // the next batch may start reading; this one waits for its last results
+    if (hip_rc == WD_OK && n_groups && hipEventRecord(slot.done, ctx->inflate_streams[0]) != hipSuccess)
+        hip_rc = WD_ERR_HIP;
+    if (hip_rc != WD_OK)
+        (void)hipDeviceSynchronize();                                    // nothing of a failed call stays in flight
+    batch_lock.unlock();
+    if (hip_rc == WD_OK && n_groups && hipEventSynchronize(slot.done) != hipSuccess)
+        hip_rc = WD_ERR_HIP;
+    if (hip_rc != WD_OK)
+        return hip_rc;
+
+    const bool want_stats = getenv("WD_INFLATE_STATS") != nullptr;
+    unsigned long long st[13] = {0};
+    for (size_t j = 0; j < job_file.size(); j++) {
+        const int i = job_file[j];
+        const InfResult &r = slot.h_res[j];
+        const uint32_t crc = (uint32_t)trailer[(size_t)i], isize = (uint32_t)(trailer[(size_t)i] >> 32);
+        const bool good = r.status == INF_OK && (size_t)r.end_byte + 8 == size[(size_t)i] && crc == r.crc &&
+                          isize == r.produced && (int64_t)r.produced == n_clusters + 4 && (int64_t)r.head == n_clusters;
+        rc[(size_t)i] = good ? WD_OK : HOST;
+        if (want_stats) {
+            const unsigned long long v[12] = {r.t_header, r.t_build, r.t_stage, r.t_pass, r.t_emit, r.t_resolve,
+                                              r.t_flush, r.t_total, r.windows, r.passes, r.rounds, r.blocks};
+            for (int q = 0; q < 12; q++)
+                st[q] += v[q];
+            st[12] += r.t_real;
+        }
+    }
+    if (want_stats && !job_file.empty()) {
+        const double nf = (double)job_file.size();
+        fprintf(stderr, "[wd inflate] files %d in %d chunks | Mclk per file: header %.2f tables %.2f stage %.2f passes %.2f "
+                        "emit %.2f resolve %.2f flush %.2f total %.2f = %.1f ms at %.2f GHz | per file: windows %.0f passes %.0f "
+                        "rounds %.0f blocks %.0f\n",
+                (int)nf, n_groups, st[0] / 1e6 / nf, st[1] / 1e6 / nf, st[2] / 1e6 / nf, st[3] / 1e6 / nf, st[4] / 1e6 / nf,
+                st[5] / 1e6 / nf, st[6] / 1e6 / nf, st[7] / 1e6 / nf, st[12] / 1e5 / nf,
+                st[12] ? (double)st[7] / (double)st[12] / 10.0 : 0.0, st[8] / nf, st[9] / nf, st[10] / nf, st[11] / nf);
+    }
+
+    // whatever the GPU decoder did not take or did not like: the host loader, whose verdict counts
+    std::vector<int> todo;
+    for (int i = 0; i < n_files; i++)
+        if (rc[(size_t)i] == HOST || rc[(size_t)i] == PENDING)
+            todo.push_back(i);
+    ctx->inflate_files_host += (long long)todo.size();
+    long long by_gpu = 0;
+    for (int i = 0; i < n_files; i++)
+        by_gpu += rc[(size_t)i] == WD_OK;
+    ctx->inflate_files_gpu += by_gpu;
+    if (!todo.empty()) {
+        std::atomic<size_t> next{0};
+        auto host = [&]() {
+            for (;;) {
+                const size_t k = next.fetch_add(1);
+                if (k >= todo.size())
+                    return;
+                const int i = todo[k];
+                rc[(size_t)i] = wd_load_bcl_gz_strided(ctx, paths[i], dst_dev[i], n_clusters, 1);
+            }
+        };
+        std::vector<std::thread> hp;
+        for (int t = 0; t < threads && (size_t)t < todo.size(); t++)
+            hp.emplace_back(host);
+        for (auto &t : hp)
+            t.join();
+    }
+    int first = WD_OK;
+    for (int i = 0; i < n_files; i++) {
+        if (rc_out)
+            rc_out[i] = rc[(size_t)i];
+        if (first == WD_OK && rc[(size_t)i] != WD_OK)
+            first = rc[(size_t)i];
+    }
+    return first;
 }
 
 int wd_load_filter(wd_ctx *ctx, const char *path, uint8_t *dst_dev, int64_t n_clusters)

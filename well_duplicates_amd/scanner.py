@@ -243,6 +243,28 @@ class Scanner:
         if rc != _lib.OK:
             _raise(self._lib, None, rc, path)
 
+    def load_bcl_gz_batch(self, paths: Sequence[str], dsts: Sequence[int], n_clusters: int, threads: int = 16,
+                          missing_ok: bool = False):
+        """Many .bcl.gz files -> device planes, inflated on the GPU (wd_load_bcl_gz_batch: host threads
+        only read the compressed files; one wave per file decodes).  Raises what load_bcl_gz raises
+        for the first file that fails; with missing_ok the files that do not exist are returned
+        (as indices) instead, for the caller to look for a .cbcl."""
+        n = len(paths)
+        enc = [os.fsencode(p) for p in paths]
+        c_paths = (ctypes.c_char_p * max(1, n))(*enc)
+        c_dsts = (ctypes.c_void_p * max(1, n))(*[int(d) for d in dsts])
+        rcs = (ctypes.c_int * max(1, n))()
+        self._lib.wd_load_bcl_gz_batch(self._ctx, n, c_paths, c_dsts, int(n_clusters), int(threads), rcs)
+        missing = []
+        for i in range(n):
+            if rcs[i] == _lib.OK:
+                continue
+            if rcs[i] == _lib.ERR_IO and missing_ok:
+                missing.append(i)
+                continue
+            _raise(self._lib, None, rcs[i], paths[i])
+        return missing
+
     def load_filter(self, path: str, dst: int, n_clusters: int):
         rc = self._lib.wd_load_filter(self._ctx, os.fsencode(path), ctypes.c_void_p(dst), int(n_clusters))
         if rc != _lib.OK:

@@ -50,8 +50,18 @@ class AllTargets:
 
     def __init__(self):
         self._by_centre = {}
-        self._wells = {}          # well index -> [Target, ...] in insertion order
+        self._wells = None        # well index -> [Target, ...] in insertion order; built on first use
         self.levels = None
+
+    def _reverse(self):
+        """The reverse index of target.py:80-83, built when first asked for (the scan path never is:
+        it works from to_csr(), and 215 000 dictionary updates are most of a targets file's parse)."""
+        if self._wells is None:
+            self._wells = {}
+            for t in self._by_centre.values():
+                for w in t.get_indices():
+                    self._wells.setdefault(w, []).append(t)
+        return self._wells
 
     def __len__(self):
         return len(self._by_centre)
@@ -72,19 +82,20 @@ class AllTargets:
         else:
             assert self.levels == t.get_levels()
         self._by_centre[t.get_centre()] = t
-        for w in t.get_indices():
-            self._wells.setdefault(w, []).append(t)
+        if self._wells is not None:
+            for w in t.get_indices():
+                self._wells.setdefault(w, []).append(t)
 
     def get_all_indices(self, level=None):
         """All well indices held; level=0 centres only, level=n that ring only (with repeats)."""
         if level == 0:
             return list(self._by_centre.keys())
         if level is None:
-            return list(self._wells.keys())
+            return list(self._reverse().keys())
         return [w for t in self for w in t.get_indices(level)]
 
     def get_from_index(self, index):
-        return [(t, t.get_level_from_index(index)) for t in self._wells.get(index, [])]
+        return [(t, t.get_level_from_index(index)) for t in self._reverse().get(index, [])]
 
     # ---------------------------------------------------------------- device layout
     def to_csr(self, levels=None):
@@ -139,8 +150,7 @@ def load_targets(filename, levels=None, limit=None):
     for ln in lines:
         if "," not in ln:
             if pending:
-                all_targets.add_target(
-                    [[int(tok) for tok in rec.split(",")] for rec in pending[:levels]])
+                all_targets.add_target([list(map(int, rec.split(","))) for rec in pending[:levels]])
                 if limit and len(all_targets) == limit:
                     break
             pending = []
