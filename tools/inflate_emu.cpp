@@ -4,7 +4,8 @@
 // match resolution, every error exit - be run under a sanitizer and compared with zlib before a
 // kernel is launched on a shared GPU.
 //
-//   g++ -O1 -g -std=c++17 -fsanitize=address,undefined -pthread tools/inflate_emu.cpp -lz -o inflate_emu
+//   g++ -O1 -g -std=c++17 -fsanitize=address,undefined -pthread [-DEMU_WAVES=1|4] [-DEMU_SPAN=512|256]
+//       tools/inflate_emu.cpp -lz -o inflate_emu
 //   ./inflate_emu file.gz [...]           decode, compare with zlib, print the statistics
 //   ./inflate_emu --fuzz SEED COUNT file.gz   corrupt the file COUNT times; the decoder must end with
 //                                          a status and, when it says OK, agree with zlib
@@ -18,37 +19,45 @@
 #include <string>
 #include <vector>
 
-// ---- the wave, emulated ---------------------------------------------------------------------
+// ---- the workgroup, emulated: NW waves of 64 lanes, one thread each --------------------------
+#ifndef EMU_WAVES
+#define EMU_WAVES 4
+#endif
 #define WD_WAVE_OPS
 #define WV_DEV inline
-static pthread_barrier_t g_bar;
-static uint32_t g_x[64];
-static thread_local int t_lane;
-inline void bar() { pthread_barrier_wait(&g_bar); }
+static pthread_barrier_t g_wbar[EMU_WAVES], g_gbar;
+static uint32_t g_x[EMU_WAVES][64];
+static thread_local int t_lane, t_wave;
+inline void bar() { pthread_barrier_wait(&g_wbar[t_wave]); }
 inline int wv_lane() { return t_lane; }
+inline int wv_wave() { return t_wave; }
+inline void wg_barrier() { pthread_barrier_wait(&g_gbar); }
+inline void wv_atomic_or(uint32_t *p, uint32_t v) { __atomic_fetch_or(p, v, __ATOMIC_SEQ_CST); }
+inline void wv_atomic_and(uint32_t *p, uint32_t v) { __atomic_fetch_and(p, v, __ATOMIC_SEQ_CST); }
+inline int __ffs(int v) { return __builtin_ffs(v); }
 inline unsigned long long wv_ballot(bool p)
 {
-    g_x[t_lane] = p;
+    g_x[t_wave][t_lane] = p;
     bar();
     unsigned long long m = 0;
     for (int i = 0; i < 64; i++)
-        m |= (unsigned long long)(g_x[i] & 1) << i;
+        m |= (unsigned long long)(g_x[t_wave][i] & 1) << i;
     bar();
     return m;
 }
 inline uint32_t wv_shfl(uint32_t v, int src)
 {
-    g_x[t_lane] = v;
+    g_x[t_wave][t_lane] = v;
     bar();
-    const uint32_t r = g_x[src & 63];
+    const uint32_t r = g_x[t_wave][src & 63];
     bar();
     return r;
 }
 inline uint32_t wv_shfl_up(uint32_t v, int d)
 {
-    g_x[t_lane] = v;
+    g_x[t_wave][t_lane] = v;
     bar();
-    const uint32_t r = t_lane >= d ? g_x[t_lane - d] : v;
+    const uint32_t r = t_lane >= d ? g_x[t_wave][t_lane - d] : v;
     bar();
     return r;
 }
@@ -77,22 +86,26 @@ struct Job {
     uint32_t out_cap;
     InfResult res;
 };
-static InfLds g_lds;
+#ifndef EMU_SPAN
+#define EMU_SPAN 512
+#endif
+static InfLdsT<EMU_WAVES, EMU_SPAN> g_lds;
 static Job g_job;
 
 static void *lane_main(void *arg)
 {
-    t_lane = (int)(intptr_t)arg;
+    t_lane = (int)(intptr_t)arg & 63;
+    t_wave = (int)(intptr_t)arg >> 6;
     inf_member(g_lds, g_job.file, g_job.file_bytes, g_job.stream_off, g_job.obase, g_job.out_cap, &g_job.res);
     return nullptr;
 }
 
 static void run_wave()
 {
-    pthread_t th[64];
-    for (int i = 0; i < 64; i++)
+    pthread_t th[EMU_WAVES * 64];
+    for (int i = 0; i < EMU_WAVES * 64; i++)
         pthread_create(&th[i], nullptr, lane_main, (void *)(intptr_t)i);
-    for (int i = 0; i < 64; i++)
+    for (int i = 0; i < EMU_WAVES * 64; i++)
         pthread_join(th[i], nullptr);
 }
 
@@ -193,7 +206,9 @@ static std::vector<uint8_t> slurp(const char *path)
 
 int main(int argc, char **argv)
 {
-    pthread_barrier_init(&g_bar, nullptr, 64);
+    for (auto &b : g_wbar)
+        pthread_barrier_init(&b, nullptr, 64);
+    pthread_barrier_init(&g_gbar, nullptr, EMU_WAVES * 64);
     int bad = 0;
     if (argc >= 5 && !strcmp(argv[1], "--fuzz")) {
         uint64_t seed = strtoull(argv[2], nullptr, 0);

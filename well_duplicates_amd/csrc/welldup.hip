@@ -228,6 +228,10 @@ struct wd_ctx {
     };
     std::mutex ingest_mu;
     std::vector<IngestSlot *> ingest_slots;
+    // the slots' streams: a few, shared (creating and destroying a stream costs milliseconds, and the
+    // copies of all slots cross the same PCIe link anyway)
+    static constexpr int kSlotStreams = 4;
+    hipStream_t slot_streams[kSlotStreams] = {};
 
     // ingest through the GPU decoder (wd_load_bcl_gz_batch): the reader threads fill a ring of
     // pinned chunks; each chunk's files are copied into the batch's arena in device memory and
@@ -244,10 +248,14 @@ struct wd_ctx {
     // times), and with a second stream for the chunk copies the next launch's files arrive while this
     // one decodes.
     static constexpr int kInflateStreams = 1;
-    static constexpr int kInflateLaunchFiles = 768;
+    static constexpr int kInflateLaunchFiles = 1024;
     size_t inflate_chunk_bytes = 16u << 20;            // option "inflate_chunk_mb" (pinning memory costs time: keep the ring small)
     InflateChunk inflate_chunks[kInflateChunks];
     size_t inflate_chunk_cap = 0;                      // bytes the chunks were allocated with
+    // options: waves per file (1, 4) and bits per lane and window (256, 512; 0 = by the launch's size:
+    // 512 bits decode a file in 33 ms but only one workgroup fits a CU (256 files at a time on the
+    // chip), 256 bits take 39 ms with two per CU)
+    int inflate_waves = 4, inflate_span = 0;
     hipStream_t inflate_streams[kInflateStreams + 1] = {};
     hipEvent_t inflate_ready[kInflateStreams] = {};    // a launch's files are all in the arena
     // what a batch keeps until its last kernel is done; two, so that the next batch's files are read
@@ -871,10 +879,11 @@ void wd_destroy(wd_ctx *ctx)
         (void)hipHostFree(sl->pinned);
         (void)hipFree(sl->dev);
         free(sl->file);
-        if (sl->stream)
-            (void)hipStreamDestroy(sl->stream);
         delete sl;
     }
+    for (auto &st : ctx->slot_streams)
+        if (st)
+            (void)hipStreamDestroy(st);
     if (ctx->own_stream)
         (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
@@ -938,6 +947,14 @@ int wd_set_option(wd_ctx *ctx, const char *name, int64_t value)
         ctx->well_stride = (int)value;
     } else if (n == "fast_inflate") {
         ctx->fast_inflate = value ? 1 : 0;
+    } else if (n == "inflate_waves") {
+        if (value != 1 && value != 4)
+            return WD_ERR_ARG;
+        ctx->inflate_waves = (int)value;
+    } else if (n == "inflate_span") {
+        if (value != 0 && value != 256 && value != 512)
+            return WD_ERR_ARG;
+        ctx->inflate_span = (int)value;
     } else if (n == "inflate_chunk_mb") {
         if (value < 1 || value > 1024)
             return WD_ERR_ARG;
@@ -983,6 +1000,8 @@ int wd_get_option(wd_ctx *ctx, const char *name, int64_t *value)
     else if (n == "dense_nt") *value = ctx->dense_nt;
     else if (n == "fast_inflate") *value = ctx->fast_inflate;
     else if (n == "inflate_chunk_mb") *value = (long long)(ctx->inflate_chunk_bytes >> 20);
+    else if (n == "inflate_waves") *value = ctx->inflate_waves;
+    else if (n == "inflate_span") *value = ctx->inflate_span;
     else if (n == "inflate_files_gpu") *value = ctx->inflate_files_gpu.load();
     else if (n == "inflate_files_host") *value = ctx->inflate_files_host.load();
     else if (n == "well_stride") *value = ctx->well_stride;
@@ -1736,10 +1755,18 @@ bool slurp_into(const char *path, uint8_t *&buf, size_t &cap, size_t *len)
 constexpr size_t kInflateSlack = 274 + 320;   // room fast_gunzip may ask for beyond the data
 #include "fast_inflate.inc"
 
-int slot_reserve(wd_ctx::IngestSlot *s, size_t need)
+int slot_reserve(wd_ctx *ctx, wd_ctx::IngestSlot *s, size_t need)
 {
-    if (!s->stream && hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking) != hipSuccess)
-        return WD_ERR_HIP;
+    if (!s->stream) {
+        std::lock_guard<std::mutex> g(ctx->ingest_mu);
+        size_t idx = 0;
+        while (idx < ctx->ingest_slots.size() && ctx->ingest_slots[idx] != s)
+            idx++;
+        hipStream_t &st = ctx->slot_streams[idx % wd_ctx::kSlotStreams];
+        if (!st && hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess)
+            return WD_ERR_HIP;
+        s->stream = st;
+    }
     if (need > s->cap) {
         (void)hipHostFree(s->pinned);
         s->pinned = nullptr;
@@ -1833,7 +1860,7 @@ int wd_load_bcl_gz_strided(wd_ctx *ctx, const char *path, uint8_t *dst_dev, int6
         return WD_ERR_IO;                                  // FileNotFoundError in the reference
     const uint8_t *raw = lease.slot->file;
     const size_t want = (size_t)n_clusters + 4;
-    int rc = slot_reserve(lease.slot, want + 64 + kInflateSlack);
+    int rc = slot_reserve(ctx, lease.slot, want + 64 + kInflateSlack);
     if (rc)
         return rc;
     size_t produced = 0;
@@ -2124,7 +2151,12 @@ int wd_load_bcl_gz_batch(wd_ctx *ctx, int n_files, const char *const *paths, uin
                     hip_rc = WD_ERR_HIP;
                     break;
                 }
-                hipLaunchKernelGGL(k_inflate, dim3(nj), dim3(64), 0, stream, slot.d_jobs + j0, slot.d_res + j0);
+                if (ctx->inflate_waves == 1)
+                hipLaunchKernelGGL((k_inflate<1, 512>), dim3(nj), dim3(64), 0, stream, slot.d_jobs + j0, slot.d_res + j0);
+            else if (ctx->inflate_span == 256 || (ctx->inflate_span == 0 && nj > 256))
+                hipLaunchKernelGGL((k_inflate<4, 256>), dim3(nj), dim3(256), 0, stream, slot.d_jobs + j0, slot.d_res + j0);
+            else
+                hipLaunchKernelGGL((k_inflate<4, 512>), dim3(nj), dim3(256), 0, stream, slot.d_jobs + j0, slot.d_res + j0);
                 hipLaunchKernelGGL(k_inflate_crc, dim3(nj), dim3(256), 0, stream, slot.d_jobs + j0,
                                    slot.d_res + j0);
                 if (hipGetLastError() != hipSuccess ||
@@ -2166,7 +2198,7 @@ int wd_load_bcl_gz_batch(wd_ctx *ctx, int n_files, const char *const *paths, uin
         return hip_rc;
 
     const bool want_stats = getenv("WD_INFLATE_STATS") != nullptr;
-    unsigned long long st[13] = {0};
+    unsigned long long st[14] = {0};
     for (size_t j = 0; j < job_file.size(); j++) {
         const int i = job_file[j];
         const InfResult &r = slot.h_res[j];
@@ -2180,15 +2212,22 @@ int wd_load_bcl_gz_batch(wd_ctx *ctx, int n_files, const char *const *paths, uin
             for (int q = 0; q < 12; q++)
                 st[q] += v[q];
             st[12] += r.t_real;
+            st[13] += r.t_res1;
         }
     }
     if (want_stats && !job_file.empty()) {
+        int occ[3] = {-1, -1, -1};
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ[0], (const void *)k_inflate<1, 512>, 64, 0);
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ[1], (const void *)k_inflate<4, 256>, 256, 0);
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ[2], (const void *)k_inflate<4, 512>, 256, 0);
+        fprintf(stderr, "[wd inflate] workgroups per CU by the runtime's count: <1,512> %d, <4,256> %d, <4,512> %d\n", occ[0],
+                occ[1], occ[2]);
         const double nf = (double)job_file.size();
         fprintf(stderr, "[wd inflate] files %d in %d chunks | Mclk per file: header %.2f tables %.2f stage %.2f passes %.2f "
-                        "emit %.2f resolve %.2f flush %.2f total %.2f = %.1f ms at %.2f GHz | per file: windows %.0f passes %.0f "
+                        "emit %.2f resolve %.2f (first sweep %.2f) flush %.2f total %.2f = %.1f ms at %.2f GHz | per file: windows %.0f passes %.0f "
                         "rounds %.0f blocks %.0f\n",
                 (int)nf, n_groups, st[0] / 1e6 / nf, st[1] / 1e6 / nf, st[2] / 1e6 / nf, st[3] / 1e6 / nf, st[4] / 1e6 / nf,
-                st[5] / 1e6 / nf, st[6] / 1e6 / nf, st[7] / 1e6 / nf, st[12] / 1e5 / nf,
+                st[5] / 1e6 / nf, st[13] / 1e6 / nf, st[6] / 1e6 / nf, st[7] / 1e6 / nf, st[12] / 1e5 / nf,
                 st[12] ? (double)st[7] / (double)st[12] / 10.0 : 0.0, st[8] / nf, st[9] / nf, st[10] / nf, st[11] / nf);
     }
 
@@ -2247,7 +2286,7 @@ int wd_load_filter(wd_ctx *ctx, const char *path, uint8_t *dst_dev, int64_t n_cl
     if (raw.size() != 12 + (size_t)n_clusters)                            // :240
         return WD_ERR_FORMAT;
     SlotLease lease(ctx);
-    int rc = slot_reserve(lease.slot, (size_t)n_clusters + 64);
+    int rc = slot_reserve(ctx, lease.slot, (size_t)n_clusters + 64);
     if (rc)
         return rc;
     if (n_clusters > 0) {
@@ -2313,7 +2352,7 @@ int wd_load_cbcl_tile(wd_ctx *ctx, const char *path, int tile_number, const uint
 
     SlotLease lease(ctx);
     wd_ctx::IngestSlot *sl = lease.slot;
-    int rc = slot_reserve(sl, (size_t)usize + 64 + kInflateSlack);
+    int rc = slot_reserve(ctx, sl, (size_t)usize + 64 + kInflateSlack);
     if (rc)
         return rc;
     size_t produced = 0;
