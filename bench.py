@@ -271,6 +271,39 @@ def e2e_probe(device, n_tiles, rows, cols, centre, lvl_off, nbr, cycles=50, thre
         host, text_h = min(run(["--host-inflate"]) for _ in range(2))
         inter, text_i = min(run(["--layout", "interleaved"]) for _ in range(2))
         plane_bytes = n_tiles * cycles * n
+        # the loaders alone on the same files: every .bcl.gz of the run directory into HBM, by the GPU
+        # decoder (wd_load_bcl_gz_batch) and by the host threads (wd_load_bcl_gz), no scan, no report
+        with Scanner(device) as sc:
+            tb = TileBatch(sc, n_tiles, cycles, n)
+            jobs = [(i, c) for i in range(n_tiles) for c in range(cycles)]
+            paths = [os.path.join(ldir, "C%d.1" % (c + 1), "s_1_%s.bcl.gz" % tiles[i]) for i, c in jobs]
+            dsts = [tb.plane_ptr(i, c) for i, c in jobs]
+
+            def gpu_load():
+                t1 = time.perf_counter()
+                sc.load_bcl_gz_batch(paths, dsts, n, threads=threads)
+                return time.perf_counter() - t1
+
+            def host_load():
+                t1 = time.perf_counter()
+                with ThreadPoolExecutor(max_workers=threads) as pool:
+                    list(pool.map(lambda k: sc.load_bcl_gz(paths[k], dsts[k], n), range(len(jobs))))
+                return time.perf_counter() - t1
+            gpu_load()
+            g0 = sc.get_option("inflate_files_gpu")
+            gpu_s = min(gpu_load() for _ in range(3))
+            on_gpu = (sc.get_option("inflate_files_gpu") - g0) // 3
+            host_load()
+            host_s = min(host_load() for _ in range(2))
+            ingest = {"files": len(jobs), "decoded_on_gpu": int(on_gpu),
+                      "gpu_inflate_seconds": round(gpu_s, 4), "gpu_inflate_plane_gb_per_s": round(plane_bytes / gpu_s / 1e9, 2),
+                      "gpu_kernel_ms_per_file": round(sc.get_option("inflate_us_per_file") / 1e3, 2),
+                      "host_inflate_seconds": round(host_s, 4),
+                      "host_inflate_plane_gb_per_s": round(plane_bytes / host_s / 1e9, 2), "threads": threads,
+                      "note": "whole-batch wall time, files in the page cache; the GPU decoder works on all files of a launch "
+                              "at once, so its time per batch is the kernel's time per file plus "
+                              "the time to read and copy the compressed bytes"}
+            tb.free()
         return {"what": "count_well_duplicates CLI (-e 2 Levenshtein, %d targets x %d levels, -q -S) on %d full-size "
                         "tiles x %d cycles of .bcl.gz files (gzip -6, 7 quality bins), warm page cache; two batches "
                         "of %d tiles" % (centre.shape[0], levels, n_tiles, cycles, max(1, n_tiles // 2)),
@@ -279,9 +312,10 @@ def e2e_probe(device, n_tiles, rows, cols, centre, lvl_off, nbr, cycles=50, thre
                 "plane_gb_per_s": round(plane_bytes / best / 1e9, 3),
                 "serial_ingest_seconds": round(serial, 4),
                 "overlap_gain": round(serial / best, 3) if best > 0 else None,
-                "inflate": "GPU (one wave per .bcl.gz file, csrc/gpu_inflate.inc); host threads only read the files",
+                "inflate": "GPU (csrc/gpu_inflate.inc: four or eight waves decode one .bcl.gz file, all files of a batch at once); host threads only read the files",
                 "host_inflate_seconds": round(host, 4),
                 "gpu_inflate_gain": round(host / best, 3) if best > 0 else None,
+                "ingest_only": ingest,
                 "interleaved_layout_seconds": round(inter, 4),
                 "interleaved_layout_note": "host inflate (the GPU decoder writes plain planes)",
                 "same_report": text == text_s == text_i == text_h, "run_dir_write_s": round(write_s, 1),

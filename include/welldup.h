@@ -216,7 +216,8 @@ int wd_load_filter(wd_ctx *ctx, const char *path, uint8_t *dst_dev, int64_t n_cl
  * reported.  rc (nullable): n_files WD_* codes; the return value is the first non-zero one.
  * One batch at a time per context (calls are serialised); safe beside the other loaders.
  * wd_get_option "inflate_files_gpu" / "inflate_files_host" count how the files of all batches were
- * decoded; option "inflate_chunk_mb" (default 16) sizes the 4 pinned staging chunks. */
+ * decoded; option "inflate_chunk_mb" (default 16) sizes the 4 pinned staging chunks, "inflate_waves"
+ * (0 = by the launch's size, 1, 4, 8) how many waves decode one file together. */
 int wd_load_bcl_gz_batch(wd_ctx *ctx, int n_files, const char *const *paths, uint8_t *const *dst_dev,
                          int64_t n_clusters, int threads, int *rc);
 /* Resident layout option for the equality / Hamming scan of sampled targets.  A line of HBM holds

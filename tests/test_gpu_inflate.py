@@ -81,7 +81,10 @@ def _load_and_check(sc, tmp_path, files, n, threads=4):
     return by_gpu, by_host
 
 
-def test_batch_matches_gzip_module(sc, tmp_path):
+@pytest.mark.parametrize("waves", [1, 4, 8])
+def test_batch_matches_gzip_module(sc, tmp_path, waves):
+    """Every kernel variant (waves per file) on every kind of stream."""
+    sc.set_option("inflate_waves", waves)
     n = 400003
     pl = _planes(n, ["q7", "q39", "q2", "noise", "runs", "period", "skew", "zeros"])
     files = {}
@@ -98,7 +101,10 @@ def test_batch_matches_gzip_module(sc, tmp_path):
     # a file name in the gzip header (FNAME), as `gzip file` writes it
     files["named"] = (gzip.compress(raw, 6)[:3] + b"\x08" + gzip.compress(raw, 6)[4:10] + b"s_1_1101.bcl\0"
                       + gzip.compress(raw, 6)[10:], pl["q7"])
-    by_gpu, by_host = _load_and_check(sc, tmp_path, files, n)
+    try:
+        by_gpu, by_host = _load_and_check(sc, tmp_path, files, n)
+    finally:
+        sc.set_option("inflate_waves", 0)
     # the decoder took everything but (some of) the all-zero planes, where one piece of the stream
     # expands more than a window holds
     assert by_gpu + by_host == len(files) and by_host <= 3, (by_gpu, by_host)

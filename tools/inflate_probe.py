@@ -25,8 +25,7 @@ ap.add_argument("--threads", default="4,16,32")
 ap.add_argument("--repeat", type=int, default=3)
 ap.add_argument("--chunk-mb", type=int, default=0)
 ap.add_argument("--no-host", action="store_true")
-ap.add_argument("--waves", type=int, default=4)
-ap.add_argument("--span", type=int, default=0)
+ap.add_argument("--waves", type=int, default=0)
 a = ap.parse_args()
 rows, cols = workload.HISEQ4000_ROWS, workload.HISEQ4000_COLS
 n = rows * cols
@@ -36,7 +35,6 @@ sc = Scanner(0)
 if a.chunk_mb:
     sc.set_option("inflate_chunk_mb", a.chunk_mb)
 sc.set_option("inflate_waves", a.waves)
-sc.set_option("inflate_span", a.span)
 tb = TileBatch(sc, a.tiles, a.cycles, n)
 tiles = [(1, 1101 + i) for i in range(a.tiles)]
 tb.fill_synthetic(spec, tiles, list(range(a.cycles)))

@@ -252,10 +252,7 @@ struct wd_ctx {
     size_t inflate_chunk_bytes = 16u << 20;            // option "inflate_chunk_mb" (pinning memory costs time: keep the ring small)
     InflateChunk inflate_chunks[kInflateChunks];
     size_t inflate_chunk_cap = 0;                      // bytes the chunks were allocated with
-    // options: waves per file (1, 4) and bits per lane and window (256, 512; 0 = by the launch's size:
-    // 512 bits decode a file in 33 ms but only one workgroup fits a CU (256 files at a time on the
-    // chip), 256 bits take 39 ms with two per CU)
-    int inflate_waves = 4, inflate_span = 0;
+    int inflate_waves = 0;                             // option: waves per file (1, 4, 8; 0 = by the launch's size)
     hipStream_t inflate_streams[kInflateStreams + 1] = {};
     hipEvent_t inflate_ready[kInflateStreams] = {};    // a launch's files are all in the arena
     // what a batch keeps until its last kernel is done; two, so that the next batch's files are read
@@ -273,6 +270,7 @@ struct wd_ctx {
     std::atomic<unsigned> inflate_calls{0};
     std::mutex inflate_mu;                             // one batch at a time reads, copies and launches
     std::atomic<long long> inflate_files_gpu{0}, inflate_files_host{0};   // how the files of all batches were decoded
+    std::atomic<long long> inflate_us_per_file{0};     // last batch: a file's time in the decode kernel, mean, microseconds
 };
 
 namespace {
@@ -948,13 +946,9 @@ int wd_set_option(wd_ctx *ctx, const char *name, int64_t value)
     } else if (n == "fast_inflate") {
         ctx->fast_inflate = value ? 1 : 0;
     } else if (n == "inflate_waves") {
-        if (value != 1 && value != 4)
+        if (value != 0 && value != 1 && value != 4 && value != 8)
             return WD_ERR_ARG;
         ctx->inflate_waves = (int)value;
-    } else if (n == "inflate_span") {
-        if (value != 0 && value != 256 && value != 512)
-            return WD_ERR_ARG;
-        ctx->inflate_span = (int)value;
     } else if (n == "inflate_chunk_mb") {
         if (value < 1 || value > 1024)
             return WD_ERR_ARG;
@@ -1001,9 +995,9 @@ int wd_get_option(wd_ctx *ctx, const char *name, int64_t *value)
     else if (n == "fast_inflate") *value = ctx->fast_inflate;
     else if (n == "inflate_chunk_mb") *value = (long long)(ctx->inflate_chunk_bytes >> 20);
     else if (n == "inflate_waves") *value = ctx->inflate_waves;
-    else if (n == "inflate_span") *value = ctx->inflate_span;
     else if (n == "inflate_files_gpu") *value = ctx->inflate_files_gpu.load();
     else if (n == "inflate_files_host") *value = ctx->inflate_files_host.load();
+    else if (n == "inflate_us_per_file") *value = ctx->inflate_us_per_file.load();
     else if (n == "well_stride") *value = ctx->well_stride;
     else if (n == "null_stream") *value = ctx->stream == nullptr ? 1 : 0;
     else if (n == "queue_first") *value = ctx->queue_first;
@@ -2151,13 +2145,16 @@ int wd_load_bcl_gz_batch(wd_ctx *ctx, int n_files, const char *const *paths, uin
                     hip_rc = WD_ERR_HIP;
                     break;
                 }
-                if (ctx->inflate_waves == 1)
-                hipLaunchKernelGGL((k_inflate<1, 512>), dim3(nj), dim3(64), 0, stream, slot.d_jobs + j0, slot.d_res + j0);
-            else if (ctx->inflate_span == 256 || (ctx->inflate_span == 0 && nj > 256))
+                // waves per file: eight while every file of the launch gets a CU of its own (26 ms per
+            // file), else four (39 ms, two files per CU); one wave per file (89 ms, three per CU) on request
+            const int waves = ctx->inflate_waves ? ctx->inflate_waves : nj <= 256 ? 8 : 4;
+            if (waves == 8)
+                hipLaunchKernelGGL((k_inflate<8, 256>), dim3(nj), dim3(512), 0, stream, slot.d_jobs + j0, slot.d_res + j0);
+            else if (waves == 4)
                 hipLaunchKernelGGL((k_inflate<4, 256>), dim3(nj), dim3(256), 0, stream, slot.d_jobs + j0, slot.d_res + j0);
             else
-                hipLaunchKernelGGL((k_inflate<4, 512>), dim3(nj), dim3(256), 0, stream, slot.d_jobs + j0, slot.d_res + j0);
-                hipLaunchKernelGGL(k_inflate_crc, dim3(nj), dim3(256), 0, stream, slot.d_jobs + j0,
+                hipLaunchKernelGGL((k_inflate<1, 512>), dim3(nj), dim3(64), 0, stream, slot.d_jobs + j0, slot.d_res + j0);
+            hipLaunchKernelGGL(k_inflate_crc, dim3(nj), dim3(256), 0, stream, slot.d_jobs + j0,
                                    slot.d_res + j0);
                 if (hipGetLastError() != hipSuccess ||
                     hipMemcpyAsync(slot.h_res + j0, slot.d_res + j0, sizeof(InfResult) * nj,
@@ -2198,7 +2195,7 @@ int wd_load_bcl_gz_batch(wd_ctx *ctx, int n_files, const char *const *paths, uin
         return hip_rc;
 
     const bool want_stats = getenv("WD_INFLATE_STATS") != nullptr;
-    unsigned long long st[14] = {0};
+    unsigned long long st[14] = {0}, real_sum = 0;
     for (size_t j = 0; j < job_file.size(); j++) {
         const int i = job_file[j];
         const InfResult &r = slot.h_res[j];
@@ -2206,6 +2203,7 @@ int wd_load_bcl_gz_batch(wd_ctx *ctx, int n_files, const char *const *paths, uin
         const bool good = r.status == INF_OK && (size_t)r.end_byte + 8 == size[(size_t)i] && crc == r.crc &&
                           isize == r.produced && (int64_t)r.produced == n_clusters + 4 && (int64_t)r.head == n_clusters;
         rc[(size_t)i] = good ? WD_OK : HOST;
+        real_sum += r.t_real;
         if (want_stats) {
             const unsigned long long v[12] = {r.t_header, r.t_build, r.t_stage, r.t_pass, r.t_emit, r.t_resolve,
                                               r.t_flush, r.t_total, r.windows, r.passes, r.rounds, r.blocks};
@@ -2215,12 +2213,14 @@ int wd_load_bcl_gz_batch(wd_ctx *ctx, int n_files, const char *const *paths, uin
             st[13] += r.t_res1;
         }
     }
+    if (!job_file.empty())
+        ctx->inflate_us_per_file = (long long)(real_sum / 100 / job_file.size());     // t_real counts 10 ns
     if (want_stats && !job_file.empty()) {
         int occ[3] = {-1, -1, -1};
         (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ[0], (const void *)k_inflate<1, 512>, 64, 0);
         (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ[1], (const void *)k_inflate<4, 256>, 256, 0);
-        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ[2], (const void *)k_inflate<4, 512>, 256, 0);
-        fprintf(stderr, "[wd inflate] workgroups per CU by the runtime's count: <1,512> %d, <4,256> %d, <4,512> %d\n", occ[0],
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ[2], (const void *)k_inflate<8, 256>, 512, 0);
+        fprintf(stderr, "[wd inflate] workgroups per CU by the runtime's count: 1 wave %d, 4 waves %d, 8 waves %d\n", occ[0],
                 occ[1], occ[2]);
         const double nf = (double)job_file.size();
         fprintf(stderr, "[wd inflate] files %d in %d chunks | Mclk per file: header %.2f tables %.2f stage %.2f passes %.2f "
