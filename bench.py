@@ -562,6 +562,33 @@ def main():
                  "alg_bytes_over_peak": round(b_il / (l_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
                 "il_lev2_T%d_l%d_L%d" % (T, levels, L), n_il, l_ms)
             il.free()
+        # the lazy gather's worst input: every read equal (amplicons, failed cycles - here all no-calls),
+        # so that no neighbour ever dies early; 8 tiles, the headline's targets, both layouts
+        if rank == 0 and world == 1 and args.interleaved_tiles > 0:
+            n_ld = min(8, args.tiles)
+            flat = synth.SynthSpec(seed=2, n_clusters=n_clusters, row=cols, nocall_per_64k=65536)
+            scratch = torch.zeros((n_ld, ncnt), dtype=torch.int64, device="cuda")
+            low = {"what": "%d tiles, every read equal: each of the %.0f neighbours of a target is a duplicate and is "
+                           "read to its last cycle" % (n_ld, compares_rank / max(1, valid_rank)),
+                   "ordinary_reads_us_per_tile": round(kern_ms / args.tiles * 1e3, 2)}
+            for stride, key in ((1, "planes"), (4, "interleaved_by_4")):
+                ld = TileBatch(sc, n_ld, L, n_clusters, interleave=stride)
+                ld.fill_synthetic(flat, lane_tile[:n_ld], list(range(L)))
+                sc.set_option("well_stride", stride)
+                for name, m2, k2 in (("equality", MODE_EQ, 0), ("levenshtein_k2", MODE_LEVENSHTEIN, 2)):
+                    sc.scan_async(ld.tables, n_ld, L, n_clusters, m2, k2, scratch.data_ptr())
+                    sc.profile_reset()
+                    for _ in range(5):
+                        sc.scan_async(ld.tables, n_ld, L, n_clusters, m2, k2, scratch.data_ptr())
+                    w_ms2, w_n2 = sc.profile_get()
+                    low["%s_%s_us_per_tile" % (key, name)] = round(w_ms2 / max(1, w_n2) / n_ld * 1e3, 2)
+                sc.set_option("well_stride", 1)
+                sc.scan_status()
+                ld.free()
+            torch.cuda.synchronize()
+            low["all_duplicates"] = bool((scratch.cpu().numpy()[:, 1 + levels:1 + 2 * levels]
+                                          == scratch.cpu().numpy()[:, 1:1 + levels]).all())
+            other["low_diversity_worst_case"] = low
     sc.set_option("profile", 0)
     # BASELINE configs[4] in small: every well of a tile is a centre (device-generated rings,
     # 3 levels), 150 bp, 2 % planted duplicates as in SURVEY.md 8d; its own context and planes

@@ -221,3 +221,44 @@ def test_corrupted_streams_end_with_a_verdict(sc, tmp_path):
         if n < stride:
             assert (sc.d2h(buf + i * stride + n, stride - n) == 0xEE).all(), i
     sc.free(buf)
+
+
+def test_filters_travel_with_the_batch(sc, tmp_path):
+    """wd_load_tile_files_batch: .filter files in the same call (copied, not decoded), checked as
+    wd_load_filter checks them (bcl_direct_reader.py:148-152, :236-240)."""
+    import struct
+    n = 50003
+    spec = synth.SynthSpec(seed=4, n_clusters=n, row=211, qual_levels=7)
+    stride = (n + 255) // 256 * 256
+    buf = sc.malloc(6 * stride)
+    sc.memset(buf, 0xEE, 6 * stride)
+    gz, want = [], []
+    for c in range(2):
+        payload = synth.plane_bytes(spec, 1, 1101, c)
+        p = tmp_path / ("c%d.bcl.gz" % c)
+        p.write_bytes(_bcl(payload))
+        gz.append(str(p))
+        want.append(payload)
+    filt = []
+    for t in (1101, 1102):
+        f = tmp_path / ("s_1_%d.filter" % t)
+        f.write_bytes(synth.filter_file_bytes(synth.filter_bytes(spec, 1, t)))
+        filt.append(str(f))
+    sc.load_bcl_gz_batch(gz, [buf, buf + stride], n, threads=3,
+                         filters=[(filt[0], buf + 2 * stride), (filt[1], buf + 3 * stride)])
+    for i in range(2):
+        assert (sc.d2h(buf + i * stride, n) == want[i]).all()
+        assert (sc.d2h(buf + (2 + i) * stride, n) == synth.filter_bytes(spec, 1, 1101 + i)).all()
+        assert (sc.d2h(buf + (2 + i) * stride + n, stride - n) == 0xEE).all()
+    # only filters, no planes
+    sc.load_bcl_gz_batch([], [], n, filters=[(filt[1], buf + 4 * stride)])
+    assert (sc.d2h(buf + 4 * stride, n) == synth.filter_bytes(spec, 1, 1102)).all()
+    bad = tmp_path / "s_1_9.filter"
+    bad.write_bytes(struct.pack("<III", 0, 2, n) + b"\1" * n)            # version != 3 (:151)
+    with pytest.raises(AssertionError, match="s_1_9"):
+        sc.load_bcl_gz_batch(gz[:1], [buf], n, filters=[(str(bad), buf + 5 * stride)])
+    with pytest.raises(AssertionError):                                  # cluster count (:236)
+        sc.load_bcl_gz_batch([], [], n + 1, filters=[(filt[0], buf + 5 * stride)])
+    with pytest.raises(FileNotFoundError, match="nope"):
+        sc.load_bcl_gz_batch(gz[:1], [buf], n, missing_ok=True, filters=[(str(tmp_path / "nope.filter"), buf + 5 * stride)])
+    sc.free(buf)

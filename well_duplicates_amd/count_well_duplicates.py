@@ -186,8 +186,12 @@ def scan_lane(sc: Scanner, reader, lane, tiles, cycle_list, mode, k, csr, wells,
         # by libwelldup (wd_load_bcl_gz).  Runs without .bcl.gz files are NovaSeq runs: the
         # tile's block of the lane/surface .cbcl is gunzipped on the host and expanded on the
         # GPU (wd_load_cbcl_tile), which needs the tile's filter first.
-        filt = [pool.submit(sc.load_filter, h.filter_file, tb.filter_ptr(i), n_clusters)
-                for i, h in enumerate(handles)]
+        jobs = [(i, c) for i in range(len(handles)) for c in range(len(cycle_list))]
+        batch = (gpu_inflate and interleave == 1 and bool(jobs)
+                 and os.path.exists(handles[0].plane_path(cycle_list[0])))
+        # (in a .bcl.gz run read in the plane layout the filters travel with the planes, below)
+        filt = [] if batch else [pool.submit(sc.load_filter, h.filter_file, tb.filter_ptr(i), n_clusters)
+                                 for i, h in enumerate(handles)]
 
         def load(i, c):
             try:
@@ -195,17 +199,18 @@ def scan_lane(sc: Scanner, reader, lane, tiles, cycle_list, mode, k, csr, wells,
             except FileNotFoundError:       # only a missing file: a corrupt one is reported as such
                 if interleave != 1:
                     raise RuntimeError("--layout interleaved reads .bcl.gz runs only") from None
-                filt[i].result()
+                if filt:
+                    filt[i].result()
                 sc.load_cbcl_tile(handles[i].cbcl_path(cycle_list[c]), int(handles[i].tile),
                                   tb.filter_ptr(i), n_clusters, tb.plane_ptr(i, c))
-        jobs = [(i, c) for i in range(len(handles)) for c in range(len(cycle_list))]
-        if gpu_inflate and interleave == 1 and jobs and os.path.exists(handles[0].plane_path(cycle_list[0])):
-            # .bcl.gz run, plane layout: the whole batch goes through the GPU decoder
-            # (wd_load_bcl_gz_batch); its reader threads are the library's own
+        if batch:
+            # the whole batch - planes and filters - goes through one call: the library's threads read
+            # the files, the GPU inflates the .bcl.gz ones (wd_load_tile_files_batch)
             def load_all():
                 missing = sc.load_bcl_gz_batch([handles[i].plane_path(cycle_list[c]) for i, c in jobs],
                                                [tb.plane_ptr(i, c) for i, c in jobs], n_clusters,
-                                               threads=max(1, threads), missing_ok=True)
+                                               threads=max(1, threads), missing_ok=True,
+                                               filters=[(h.filter_file, tb.filter_ptr(i)) for i, h in enumerate(handles)])
                 for j in missing:           # (a run is .bcl.gz or .cbcl, never both: this loop is for the odd file)
                     load(*jobs[j])
             planes = [pool.submit(load_all)]

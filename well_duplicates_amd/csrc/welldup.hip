@@ -1996,6 +1996,12 @@ int inflate_prepare(wd_ctx *ctx, wd_ctx::InflateSlot &sl, int n_chunks, size_t a
 int wd_load_bcl_gz_batch(wd_ctx *ctx, int n_files, const char *const *paths, uint8_t *const *dst_dev,
                          int64_t n_clusters, int threads, int *rc_out)
 {
+    return wd_load_tile_files_batch(ctx, n_files, paths, dst_dev, nullptr, n_clusters, threads, rc_out);
+}
+
+int wd_load_tile_files_batch(wd_ctx *ctx, int n_files, const char *const *paths, uint8_t *const *dst_dev,
+                             const uint8_t *is_filter, int64_t n_clusters, int threads, int *rc_out)
+{
     if (!ctx || n_files < 0 || (n_files && (!paths || !dst_dev)) || n_clusters < 0 || n_clusters > 0x7FFFFFF0ll)
         return WD_ERR_ARG;
     if (hipSetDevice(ctx->device) != hipSuccess)
@@ -2024,7 +2030,10 @@ int wd_load_bcl_gz_batch(wd_ctx *ctx, int n_files, const char *const *paths, uin
             rc[(size_t)i] = WD_ERR_ARG;
         } else if (stat(paths[i], &st) != 0 || !S_ISREG(st.st_mode)) {
             rc[(size_t)i] = WD_ERR_IO;                                   // FileNotFoundError in the reference
-        } else if ((size_t)st.st_size + 16 > chunk_bytes || st.st_size < 18 || (uint64_t)st.st_size > 0x1FFFFFF0ull) {
+        } else if (is_filter && is_filter[i] && (st.st_size < 12 || (int64_t)st.st_size != 12 + n_clusters)) {
+            rc[(size_t)i] = WD_ERR_FORMAT;                               // bcl_direct_reader.py:240
+        } else if ((size_t)st.st_size + 16 > chunk_bytes || st.st_size < 12 || (uint64_t)st.st_size > 0x1FFFFFF0ull ||
+                   (st.st_size < 18 && !(is_filter && is_filter[i]))) {
             rc[(size_t)i] = HOST;
         } else {
             size[(size_t)i] = (size_t)st.st_size;
@@ -2086,10 +2095,16 @@ int wd_load_bcl_gz_batch(wd_ctx *ctx, int n_files, const char *const *paths, uin
                 ok = got == sz;
                 close(fd);
             }
-            if (!ok || !inf_gzip_header(dst, sz, &stream_off[(size_t)i]))
+            if (ok && is_filter && is_filter[i]) {                       // .filter: header 0, 3, n (:148-152, :236), then the bytes
+                uint32_t head[3];
+                memcpy(head, dst, 12);
+                if (head[0] != 0 || head[1] != 3 || (int64_t)head[2] != n_clusters)
+                    rc[(size_t)i] = WD_ERR_FORMAT;
+            } else if (!ok || !inf_gzip_header(dst, sz, &stream_off[(size_t)i])) {
                 rc[(size_t)i] = HOST;                                    // let the host path say what is wrong with it
-            else
+            } else {
                 memcpy(&trailer[(size_t)i], dst + sz - 8, 8);
+            }
             if (groups[(size_t)g]->remaining.fetch_sub(1) == 1) {
                 std::lock_guard<std::mutex> lk(mu);
                 cv.notify_all();
@@ -2116,9 +2131,14 @@ int wd_load_bcl_gz_batch(wd_ctx *ctx, int n_files, const char *const *paths, uin
         }
         wd_ctx::InflateChunk &ch = ctx->inflate_chunks[g % kChunks];
         uint8_t *dev = slot.arena + grp.arena_at;
+        std::vector<int> plain;                                          // .filter files of the chunk: copied, not decoded
         for (int i = grp.first; i <= grp.last; i++) {
             if (group_of[(size_t)i] != g || rc[(size_t)i] != PENDING)
                 continue;
+            if (is_filter && is_filter[i]) {
+                plain.push_back(i);
+                continue;
+            }
             InfJob &j = slot.h_jobs[job_file.size()];
             j.file = reinterpret_cast<const uint32_t *>(dev + offset[(size_t)i]);
             j.obase = dst_dev[i] - 4;
@@ -2133,6 +2153,16 @@ int wd_load_bcl_gz_batch(wd_ctx *ctx, int n_files, const char *const *paths, uin
             hip_rc = WD_ERR_HIP;
             break;
         }
+        for (int i : plain) {
+            if (n_clusters > 0 && hipMemcpyAsync(dst_dev[i], dev + offset[(size_t)i] + 12, (size_t)n_clusters,
+                                                  hipMemcpyDeviceToDevice, copy_stream) != hipSuccess) {
+                hip_rc = WD_ERR_HIP;
+                break;
+            }
+            rc[(size_t)i] = WD_OK;                                       // (the call returns after the copy stream has drained)
+        }
+        if (hip_rc != WD_OK)
+            break;
         // enough files for a launch, or the last chunk: decode them
         if (g + 1 == n_groups || job_file.size() - j0 >= (size_t)wd_ctx::kInflateLaunchFiles) {
             const unsigned nj = (unsigned)(job_file.size() - j0);
@@ -2184,7 +2214,11 @@ int wd_load_bcl_gz_batch(wd_ctx *ctx, int n_files, const char *const *paths, uin
     for (auto &t : pool)
         t.join();
     // the next batch may start reading; this one waits for its last results
-    if (hip_rc == WD_OK && n_groups && hipEventRecord(slot.done, ctx->inflate_streams[0]) != hipSuccess)
+    // (.filter copies ride on the copy stream: the decode stream's event must come after them)
+    if (hip_rc == WD_OK && n_groups &&
+        (hipEventRecord(ctx->inflate_ready[0], copy_stream) != hipSuccess ||
+         hipStreamWaitEvent(ctx->inflate_streams[0], ctx->inflate_ready[0], 0) != hipSuccess ||
+         hipEventRecord(slot.done, ctx->inflate_streams[0]) != hipSuccess))
         hip_rc = WD_ERR_HIP;
     if (hip_rc != WD_OK)
         (void)hipDeviceSynchronize();                                    // nothing of a failed call stays in flight
@@ -2239,7 +2273,7 @@ int wd_load_bcl_gz_batch(wd_ctx *ctx, int n_files, const char *const *paths, uin
     ctx->inflate_files_host += (long long)todo.size();
     long long by_gpu = 0;
     for (int i = 0; i < n_files; i++)
-        by_gpu += rc[(size_t)i] == WD_OK;
+        by_gpu += rc[(size_t)i] == WD_OK && !(is_filter && is_filter[i]);
     ctx->inflate_files_gpu += by_gpu;
     if (!todo.empty()) {
         std::atomic<size_t> next{0};
@@ -2249,7 +2283,8 @@ int wd_load_bcl_gz_batch(wd_ctx *ctx, int n_files, const char *const *paths, uin
                 if (k >= todo.size())
                     return;
                 const int i = todo[k];
-                rc[(size_t)i] = wd_load_bcl_gz_strided(ctx, paths[i], dst_dev[i], n_clusters, 1);
+                rc[(size_t)i] = is_filter && is_filter[i] ? wd_load_filter(ctx, paths[i], dst_dev[i], n_clusters)
+                                                          : wd_load_bcl_gz_strided(ctx, paths[i], dst_dev[i], n_clusters, 1);
             }
         };
         std::vector<std::thread> hp;

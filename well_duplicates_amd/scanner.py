@@ -244,22 +244,27 @@ class Scanner:
             _raise(self._lib, None, rc, path)
 
     def load_bcl_gz_batch(self, paths: Sequence[str], dsts: Sequence[int], n_clusters: int, threads: int = 16,
-                          missing_ok: bool = False):
+                          missing_ok: bool = False, filters: Sequence = ()):
         """Many .bcl.gz files -> device planes, inflated on the GPU (wd_load_bcl_gz_batch: host threads
         only read the compressed files; one wave per file decodes).  Raises what load_bcl_gz raises
         for the first file that fails; with missing_ok the files that do not exist are returned
-        (as indices) instead, for the caller to look for a .cbcl."""
+        (as indices) instead, for the caller to look for a .cbcl.  filters: [(path, dst)] of the
+        tiles' .filter files, loaded in the same call (a missing one always raises)."""
+        n_gz = len(paths)
+        paths = list(paths) + [f[0] for f in filters]
+        dsts = list(dsts) + [f[1] for f in filters]
         n = len(paths)
         enc = [os.fsencode(p) for p in paths]
         c_paths = (ctypes.c_char_p * max(1, n))(*enc)
         c_dsts = (ctypes.c_void_p * max(1, n))(*[int(d) for d in dsts])
+        kinds = (ctypes.c_uint8 * max(1, n))(*([0] * n_gz + [1] * (n - n_gz)))
         rcs = (ctypes.c_int * max(1, n))()
-        self._lib.wd_load_bcl_gz_batch(self._ctx, n, c_paths, c_dsts, int(n_clusters), int(threads), rcs)
+        self._lib.wd_load_tile_files_batch(self._ctx, n, c_paths, c_dsts, kinds, int(n_clusters), int(threads), rcs)
         missing = []
         for i in range(n):
             if rcs[i] == _lib.OK:
                 continue
-            if rcs[i] == _lib.ERR_IO and missing_ok:
+            if rcs[i] == _lib.ERR_IO and missing_ok and i < n_gz:
                 missing.append(i)
                 continue
             _raise(self._lib, None, rcs[i], paths[i])
