@@ -253,6 +253,17 @@ int wd_gunzip(const uint8_t *src, size_t src_len, uint8_t *dst, size_t dst_cap, 
  * wd_load_bcl_gz. */
 int wd_load_cbcl_tile(wd_ctx *ctx, const char *path, int tile_number, const uint8_t *filter_dev,
                       int64_t n_clusters, uint8_t *dst_dev);
+/* A batch of tile blocks, inflated on the GPU: entry i = the block of tile tile_number[i] in the .cbcl
+ * file paths[i] -> dst_dev[i], as n calls of wd_load_cbcl_tile would (bcl_direct_reader.py:255-325;
+ * filter_dev[i] must already hold the tile's filter bytes).  The files' headers and tile tables are
+ * read once per file on the host; reader threads bring the blocks into pinned memory; one launch of the
+ * DEFLATE kernel (csrc/gpu_inflate.inc) decodes them into packed planes, which the expansion kernels
+ * turn into byte planes.  CRC-32 and length of every block are checked; an entry the GPU decoder
+ * declines or whose checks fail is loaded again by wd_load_cbcl_tile, whose return code is reported.
+ * rc (nullable): n WD_* codes; the return value is the first non-zero one. */
+int wd_load_cbcl_batch(wd_ctx *ctx, int n, const char *const *paths, const int *tile_number,
+                       const uint8_t *const *filter_dev, uint8_t *const *dst_dev, int64_t n_clusters, int threads,
+                       int *rc);
 int wd_gather_wells(wd_ctx *ctx, const uint8_t *const *planes, int L, const int32_t *idx, int64_t n,
                     int64_t n_clusters, uint8_t *out_host);
 

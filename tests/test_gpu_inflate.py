@@ -262,3 +262,47 @@ def test_filters_travel_with_the_batch(sc, tmp_path):
     with pytest.raises(FileNotFoundError, match="nope"):
         sc.load_bcl_gz_batch(gz[:1], [buf], n, missing_ok=True, filters=[(str(tmp_path / "nope.filter"), buf + 5 * stride)])
     sc.free(buf)
+
+
+@pytest.mark.parametrize("excluded", [False, True])
+def test_cbcl_blocks_through_the_gpu_decoder(sc, tmp_path, excluded):
+    """wd_load_cbcl_batch = wd_load_cbcl_tile entry by entry (bcl_direct_reader.py:255-325): the tiles'
+    gzip blocks inflated in one launch, expanded with the excluded-wells indirection."""
+    from well_duplicates_amd import bcl
+    from well_duplicates_amd.scanner import TileBatch
+    n = 70001
+    spec = synth.SynthSpec(seed=12, n_clusters=n, row=211, nocall_per_64k=5000, pass_per_64k=40000)
+    tiles = ["1101", "1150", "2103"]
+    cycles = list(range(4))
+    synth.write_run_dir_cbcl(spec, str(tmp_path), [2], tiles, cycles, excluded=excluded)
+    rd = bcl.BCLReader(str(tmp_path))
+    handles = [rd.get_tile(2, t) for t in tiles]
+    one = TileBatch(sc, len(tiles), len(cycles), n)
+    many = TileBatch(sc, len(tiles), len(cycles), n)
+    for tb in (one, many):
+        sc.load_bcl_gz_batch([], [], n, filters=[(h.filter_file, tb.filter_ptr(i)) for i, h in enumerate(handles)])
+    jobs = [(i, c) for i in range(len(tiles)) for c in cycles]
+    for i, c in jobs:
+        sc.load_cbcl_tile(handles[i].cbcl_path(c), int(tiles[i]), one.filter_ptr(i), n, one.plane_ptr(i, c))
+    g0, h0 = sc.get_option("inflate_files_gpu"), sc.get_option("inflate_files_host")
+    sc.load_cbcl_batch([(handles[i].cbcl_path(c), int(tiles[i]), many.filter_ptr(i), many.plane_ptr(i, c)) for i, c in jobs],
+                       n, threads=3)
+    assert sc.get_option("inflate_files_gpu") - g0 == len(jobs) and sc.get_option("inflate_files_host") == h0
+    for i, c in jobs:
+        assert (many.download_plane(i, c) == one.download_plane(i, c)).all(), (i, c)
+    # errors are the single-entry loader's: a tile that is not in the table (:295), a missing file
+    with pytest.raises(AssertionError):
+        sc.load_cbcl_batch([(handles[0].cbcl_path(0), 1199, many.filter_ptr(0), many.plane_ptr(0, 0))], n)
+    with pytest.raises(FileNotFoundError, match="nope"):
+        sc.load_cbcl_batch([(handles[0].cbcl_path(0), 1101, many.filter_ptr(0), many.plane_ptr(0, 0)),
+                            (str(tmp_path / "nope.cbcl"), 1101, many.filter_ptr(0), many.plane_ptr(0, 1))], n)
+    # a damaged block goes to the host loader, which reports it
+    raw = bytearray(open(handles[1].cbcl_path(1), "rb").read())
+    for pos in range(len(raw) - 400, len(raw) - 300):
+        raw[pos] ^= 0x5A
+    bad = tmp_path / "damaged.cbcl"
+    bad.write_bytes(bytes(raw))
+    with pytest.raises((zlib.error, gzip.BadGzipFile, EOFError, IndexError, AssertionError)):
+        sc.load_cbcl_batch([(str(bad), int(tiles[-1]), many.filter_ptr(2), many.plane_ptr(2, 1))], n)
+    one.free()
+    many.free()

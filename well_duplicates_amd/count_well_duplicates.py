@@ -187,9 +187,13 @@ def scan_lane(sc: Scanner, reader, lane, tiles, cycle_list, mode, k, csr, wells,
         # tile's block of the lane/surface .cbcl is gunzipped on the host and expanded on the
         # GPU (wd_load_cbcl_tile), which needs the tile's filter first.
         jobs = [(i, c) for i in range(len(handles)) for c in range(len(cycle_list))]
-        batch = (gpu_inflate and interleave == 1 and bool(jobs)
-                 and os.path.exists(handles[0].plane_path(cycle_list[0])))
-        # (in a .bcl.gz run read in the plane layout the filters travel with the planes, below)
+        batch = None                        # which files the GPU decoder gets as one batch
+        if gpu_inflate and interleave == 1 and jobs:
+            if os.path.exists(handles[0].plane_path(cycle_list[0])):
+                batch = "bcl.gz"
+            elif os.path.exists(handles[0].cbcl_path(cycle_list[0])):
+                batch = "cbcl"
+        # (in a batch the filters travel with the planes, below)
         filt = [] if batch else [pool.submit(sc.load_filter, h.filter_file, tb.filter_ptr(i), n_clusters)
                                  for i, h in enumerate(handles)]
 
@@ -203,7 +207,16 @@ def scan_lane(sc: Scanner, reader, lane, tiles, cycle_list, mode, k, csr, wells,
                     filt[i].result()
                 sc.load_cbcl_tile(handles[i].cbcl_path(cycle_list[c]), int(handles[i].tile),
                                   tb.filter_ptr(i), n_clusters, tb.plane_ptr(i, c))
-        if batch:
+        if batch == "cbcl":
+            # NovaSeq: the filters first (the expansion of a tile's blocks needs its filter in HBM),
+            # then every (tile, cycle) block of the batch through one launch of the GPU decoder
+            def load_all():
+                sc.load_bcl_gz_batch([], [], n_clusters, threads=max(1, threads),
+                                     filters=[(h.filter_file, tb.filter_ptr(i)) for i, h in enumerate(handles)])
+                sc.load_cbcl_batch([(handles[i].cbcl_path(cycle_list[c]), int(handles[i].tile), tb.filter_ptr(i),
+                                     tb.plane_ptr(i, c)) for i, c in jobs], n_clusters, threads=max(1, threads))
+            planes = [pool.submit(load_all)]
+        elif batch:
             # the whole batch - planes and filters - goes through one call: the library's threads read
             # the files, the GPU inflates the .bcl.gz ones (wd_load_tile_files_batch)
             def load_all():

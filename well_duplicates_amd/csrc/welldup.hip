@@ -2439,6 +2439,337 @@ int wd_load_cbcl_tile(wd_ctx *ctx, const char *path, int tile_number, const uint
     return WD_OK;
 }
 
+// ---- a batch of NovaSeq tile blocks through the GPU decoder -----------------------------------
+// Entry i: the block of tile tile_number[i] in the .cbcl file paths[i] (all tiles of a surface share
+// one file per cycle) -> an n_clusters-byte plane at dst_dev[i], exactly what wd_load_cbcl_tile does
+// (bcl_direct_reader.py:255-325).  The files' headers and tile tables are parsed on the host (once
+// per file), reader threads bring the tiles' gzip blocks into the pinned ring, the GPU inflates them
+// (one launch for the batch) into packed planes in the arena and expands those (nibble -> byte, the
+// excluded-wells indirection through the tile's filter, which must already be in filter_dev[i]).
+// An entry the GPU decoder declines or whose checks fail (CRC-32, length) goes through
+// wd_load_cbcl_tile, whose return code is reported; so do the table checks' failures.
+int wd_load_cbcl_batch(wd_ctx *ctx, int n, const char *const *paths, const int *tile_number,
+                       const uint8_t *const *filter_dev, uint8_t *const *dst_dev, int64_t n_clusters, int threads,
+                       int *rc_out)
+{
+    if (!ctx || n < 0 || (n && (!paths || !tile_number || !filter_dev || !dst_dev)) || n_clusters < 0 ||
+        n_clusters > 0x7FFFFFF0ll)
+        return WD_ERR_ARG;
+    if (hipSetDevice(ctx->device) != hipSuccess)
+        return WD_ERR_HIP;
+    wd_ctx::InflateSlot &slot = ctx->inflate_slots[ctx->inflate_calls.fetch_add(1) & 1];
+    std::lock_guard<std::mutex> slot_lock(slot.mu);
+    std::unique_lock<std::mutex> batch_lock(ctx->inflate_mu);
+    threads = std::max(1, std::min(threads, 256));
+    constexpr int kChunks = wd_ctx::kInflateChunks, kStreams = wd_ctx::kInflateStreams;
+    const size_t chunk_bytes = ctx->inflate_chunk_bytes;
+    enum : int { PENDING = 1, HOST = 2 };
+    struct Entry { uint64_t pos = 0; uint32_t usize = 0, csize = 0, stream_off = 0; int excluded = 0; };
+    std::vector<Entry> ent((size_t)n);
+    std::vector<int> rc((size_t)n, PENDING);
+    // the tile tables, once per file (:263-295)
+    {
+        std::vector<int> order((size_t)n);
+        for (int i = 0; i < n; i++)
+            order[(size_t)i] = i;
+        std::sort(order.begin(), order.end(), [&](int a, int b) {
+            const int c = paths[a] && paths[b] ? strcmp(paths[a], paths[b]) : (paths[a] ? 1 : 0) - (paths[b] ? 1 : 0);
+            return c < 0 || (c == 0 && a < b);
+        });
+        for (size_t k = 0; k < order.size();) {
+            size_t k1 = k;
+            const char *path = paths[order[k]];
+            while (k1 < order.size() && paths[order[k1]] && path && strcmp(paths[order[k1]], path) == 0)
+                k1++;
+            if (k1 == k)
+                k1 = k + 1;
+            int file_rc = WD_OK;
+            std::vector<uint8_t> offs;
+            uint32_t hsize = 0, tile_count = 0;
+            FILE *f = path ? fopen(path, "rb") : nullptr;
+            if (!path) {
+                file_rc = WD_ERR_ARG;
+            } else if (!f) {
+                file_rc = WD_ERR_IO;
+            } else {
+                uint8_t head[12];
+                uint16_t version = 0;
+                uint32_t bins = 0;
+                if (fread(head, 1, 12, f) != 12) {
+                    file_rc = WD_ERR_FORMAT;
+                } else {
+                    memcpy(&version, head, 2);
+                    memcpy(&hsize, head + 2, 4);
+                    memcpy(&bins, head + 8, 4);
+                    if (version != 1 || hsize <= 32 || head[6] != 2 || head[7] != 2 || bins != 4)   // :266-270
+                        file_rc = WD_ERR_FORMAT;
+                }
+                if (file_rc == WD_OK) {
+                    std::vector<uint8_t> tab((size_t)bins * 8 + 4);
+                    if (fread(tab.data(), 1, tab.size(), f) != tab.size()) {
+                        file_rc = WD_ERR_FORMAT;
+                    } else {
+                        memcpy(&tile_count, tab.data() + tab.size() - 4, 4);
+                        offs.resize((size_t)tile_count * 16 + 1);
+                        if (tile_count > (1u << 20) || fread(offs.data(), 1, offs.size(), f) != offs.size())
+                            file_rc = WD_ERR_FORMAT;
+                    }
+                }
+                fclose(f);
+            }
+            for (size_t q = k; q < k1; q++) {
+                const int i = order[q];
+                if (file_rc != WD_OK || !dst_dev[i] || !filter_dev[i]) {
+                    rc[(size_t)i] = file_rc != WD_OK ? file_rc : WD_ERR_ARG;
+                    continue;
+                }
+                uint64_t pos = hsize;
+                bool found = false;
+                for (uint32_t t = 0; t < tile_count; t++) {
+                    uint32_t rec[4];
+                    memcpy(rec, offs.data() + (size_t)t * 16, 16);
+                    if ((int)rec[0] == tile_number[i]) {
+                        ent[(size_t)i].pos = pos;
+                        ent[(size_t)i].usize = rec[2];
+                        ent[(size_t)i].csize = rec[3];
+                        ent[(size_t)i].excluded = offs.back() ? 1 : 0;
+                        found = true;
+                        break;
+                    }
+                    pos += rec[3];
+                }
+                if (!found)
+                    rc[(size_t)i] = WD_ERR_FORMAT;                       // assert t_number == tile_as_int (:295)
+            }
+            k = k1;
+        }
+    }
+    // chunks of the ring, room in the arena: [compressed blocks][packed planes + chunk sums]
+    const int exp_chunks = (int)((n_clusters + kCbclChunk - 1) / kCbclChunk);
+    std::vector<size_t> offset((size_t)n, 0), out_at((size_t)n, 0);
+    std::vector<int> group_of((size_t)n, -1);
+    struct Group { int first, last; size_t bytes, arena_at; std::atomic<int> remaining{0}; };
+    std::vector<std::unique_ptr<Group>> groups;
+    size_t comp_bytes = 0, out_bytes = 0, n_jobs = 0;
+    for (int i = 0; i < n; i++) {
+        if (rc[(size_t)i] != PENDING)
+            continue;
+        const Entry &e = ent[(size_t)i];
+        if ((size_t)e.csize + 32 > chunk_bytes || e.csize < 18 || e.usize == 0 || e.usize > 0x3FFFFFF0u) {
+            rc[(size_t)i] = HOST;
+            continue;
+        }
+        const size_t padded = ((size_t)e.csize + 15) & ~(size_t)15;
+        if (groups.empty() || groups.back()->bytes + padded > chunk_bytes)
+            groups.emplace_back(new Group{i, i, 0, comp_bytes});
+        Group &g = *groups.back();
+        offset[(size_t)i] = g.bytes;
+        g.bytes += padded;
+        comp_bytes += padded;
+        g.last = i;
+        g.remaining.fetch_add(1);
+        group_of[(size_t)i] = (int)groups.size() - 1;
+        out_at[(size_t)i] = out_bytes;
+        out_bytes += (((size_t)e.usize + 255) & ~(size_t)255) + (size_t)std::max(exp_chunks, 1) * 4 + 252;
+        n_jobs++;
+    }
+    const int n_groups = (int)groups.size();
+    if (n_groups) {
+        const int prc = inflate_prepare(ctx, slot, std::min(n_groups, kChunks), comp_bytes + out_bytes + 256, n_jobs);
+        if (prc)
+            return prc;
+        if (hipStreamSynchronize(ctx->inflate_streams[kStreams]) != hipSuccess)
+            return WD_ERR_HIP;
+    }
+    uint8_t *out_base = slot.arena ? slot.arena + ((comp_bytes + 255) & ~(size_t)255) : nullptr;
+    std::vector<uint64_t> trailer((size_t)n, 0);
+    std::mutex mu;
+    std::condition_variable cv;
+    int free_upto = kChunks;
+    bool abort_all = false;
+    std::atomic<int> next_file{0};
+    auto reader = [&]() {
+        for (;;) {
+            const int i = next_file.fetch_add(1);
+            if (i >= n)
+                return;
+            const int g = group_of[(size_t)i];
+            if (g < 0)
+                continue;
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv.wait(lk, [&] { return abort_all || g < free_upto; });
+                if (abort_all)
+                    return;
+            }
+            Entry &e = ent[(size_t)i];
+            uint8_t *dst = ctx->inflate_chunks[g % kChunks].pinned + offset[(size_t)i];
+            bool ok = false;
+            const int fd = open(paths[i], O_RDONLY);
+            if (fd >= 0) {
+                size_t got = 0;
+                while (got < e.csize) {
+                    const ssize_t k = pread(fd, dst + got, e.csize - got, (off_t)(e.pos + got));
+                    if (k <= 0)
+                        break;
+                    got += (size_t)k;
+                }
+                ok = got == e.csize;
+                close(fd);
+            }
+            if (!ok || !inf_gzip_header(dst, e.csize, &e.stream_off))
+                rc[(size_t)i] = HOST;
+            else
+                memcpy(&trailer[(size_t)i], dst + e.csize - 8, 8);
+            if (groups[(size_t)g]->remaining.fetch_sub(1) == 1) {
+                std::lock_guard<std::mutex> lk(mu);
+                cv.notify_all();
+            }
+        }
+    };
+    std::vector<std::thread> pool;
+    for (int t = 0; t < threads && t < std::max(1, n); t++)
+        pool.emplace_back(reader);
+    std::vector<int> job_file;
+    job_file.reserve(n_jobs);
+    int hip_rc = WD_OK;
+    hipStream_t copy_stream = ctx->inflate_streams[kStreams], stream = ctx->inflate_streams[0];
+    for (int g = 0; g < n_groups && hip_rc == WD_OK; g++) {
+        Group &grp = *groups[(size_t)g];
+        {
+            std::unique_lock<std::mutex> lk(mu);
+            cv.wait(lk, [&] { return grp.remaining.load() == 0; });
+        }
+        wd_ctx::InflateChunk &ch = ctx->inflate_chunks[g % kChunks];
+        uint8_t *dev = slot.arena + grp.arena_at;
+        for (int i = grp.first; i <= grp.last; i++) {
+            if (group_of[(size_t)i] != g || rc[(size_t)i] != PENDING)
+                continue;
+            InfJob &j = slot.h_jobs[job_file.size()];
+            j.file = reinterpret_cast<const uint32_t *>(dev + offset[(size_t)i]);
+            j.obase = out_base + out_at[(size_t)i];
+            j.file_bytes = ent[(size_t)i].csize;
+            j.stream_off = ent[(size_t)i].stream_off;
+            j.out_cap = ent[(size_t)i].usize;
+            j.pad_ = 0;
+            job_file.push_back(i);
+        }
+        if (hipMemcpyAsync(dev, ch.pinned, grp.bytes, hipMemcpyHostToDevice, copy_stream) != hipSuccess ||
+            hipEventRecord(ch.copied, copy_stream) != hipSuccess) {
+            hip_rc = WD_ERR_HIP;
+            break;
+        }
+        if (g + 1 >= kChunks) {
+            if (hipEventSynchronize(ctx->inflate_chunks[(g + 1) % kChunks].copied) != hipSuccess) {
+                hip_rc = WD_ERR_HIP;
+                break;
+            }
+            std::lock_guard<std::mutex> lk(mu);
+            free_upto = g + 2;
+            cv.notify_all();
+        }
+    }
+    const unsigned nj = (unsigned)job_file.size();
+    if (hip_rc == WD_OK && nj) {                             // one launch for the batch, then the expansions
+        if (hipEventRecord(ctx->inflate_ready[0], copy_stream) != hipSuccess ||
+            hipStreamWaitEvent(stream, ctx->inflate_ready[0], 0) != hipSuccess ||
+            hipMemcpyAsync(slot.d_jobs, slot.h_jobs, sizeof(InfJob) * nj, hipMemcpyHostToDevice, stream) != hipSuccess)
+            hip_rc = WD_ERR_HIP;
+    }
+    if (hip_rc == WD_OK && nj) {
+        const int waves = ctx->inflate_waves ? ctx->inflate_waves : nj <= 256 ? 8 : 4;
+        if (waves == 8)
+            hipLaunchKernelGGL((k_inflate<8, 256>), dim3(nj), dim3(512), 0, stream, slot.d_jobs, slot.d_res);
+        else if (waves == 4)
+            hipLaunchKernelGGL((k_inflate<4, 256>), dim3(nj), dim3(256), 0, stream, slot.d_jobs, slot.d_res);
+        else
+            hipLaunchKernelGGL((k_inflate<1, 512>), dim3(nj), dim3(64), 0, stream, slot.d_jobs, slot.d_res);
+        hipLaunchKernelGGL(k_inflate_crc, dim3(nj), dim3(256), 0, stream, slot.d_jobs, slot.d_res);
+        hipLaunchKernelGGL(k_inflate_heads, dim3((nj + 255) / 256), dim3(256), 0, stream, slot.d_jobs, slot.d_res, (int)nj);
+        // (the expansions take the table's block length on trust; the results below say whether it held)
+        for (unsigned q = 0; q < nj && n_clusters > 0; q++) {
+            const int i = job_file[q];
+            const Entry &e = ent[(size_t)i];
+            uint8_t *packed = out_base + out_at[(size_t)i];
+            uint32_t *sums = (uint32_t *)(packed + (((size_t)e.usize + 255) & ~(size_t)255));
+            if (e.excluded) {
+                hipLaunchKernelGGL(k_cbcl_count, dim3(exp_chunks), dim3(kBlock), 0, stream, filter_dev[i], (long long)n_clusters,
+                                   sums);
+                hipLaunchKernelGGL(k_cbcl_scan, dim3(1), dim3(kBlock), 0, stream, sums, exp_chunks);
+            }
+            hipLaunchKernelGGL(k_cbcl_expand, dim3(exp_chunks), dim3(kBlock), 0, stream, packed, (long long)e.usize * 2,
+                               filter_dev[i], sums, (long long)n_clusters, e.excluded, dst_dev[i]);
+        }
+        if (hipGetLastError() != hipSuccess ||
+            hipMemcpyAsync(slot.h_res, slot.d_res, sizeof(InfResult) * nj, hipMemcpyDeviceToHost, stream) != hipSuccess)
+            hip_rc = WD_ERR_HIP;
+    }
+    if (hip_rc != WD_OK) {
+        std::lock_guard<std::mutex> lk(mu);
+        abort_all = true;
+        cv.notify_all();
+    }
+    for (auto &t : pool)
+        t.join();
+    if (hip_rc == WD_OK && n_groups && hipEventRecord(slot.done, stream) != hipSuccess)
+        hip_rc = WD_ERR_HIP;
+    if (hip_rc != WD_OK)
+        (void)hipDeviceSynchronize();
+    batch_lock.unlock();
+    if (hip_rc == WD_OK && n_groups && hipEventSynchronize(slot.done) != hipSuccess)
+        hip_rc = WD_ERR_HIP;
+    if (hip_rc != WD_OK)
+        return hip_rc;
+    unsigned long long real_sum = 0;
+    for (size_t j = 0; j < job_file.size(); j++) {
+        const int i = job_file[j];
+        const InfResult &r = slot.h_res[j];
+        const Entry &e = ent[(size_t)i];
+        const uint32_t crc = (uint32_t)trailer[(size_t)i], isize = (uint32_t)(trailer[(size_t)i] >> 32);
+        const bool good = r.status == INF_OK && (size_t)r.end_byte + 8 == e.csize && crc == r.crc && isize == r.produced &&
+                          r.produced == e.usize;
+        // (a block shorter than the tile without excluded wells: the host path's IndexError)
+        rc[(size_t)i] = good && (e.excluded || (long long)e.usize * 2 >= n_clusters) ? WD_OK : HOST;
+        real_sum += r.t_real;
+    }
+    if (!job_file.empty())
+        ctx->inflate_us_per_file = (long long)(real_sum / 100 / job_file.size());
+    std::vector<int> todo;
+    long long by_gpu = 0;
+    for (int i = 0; i < n; i++) {
+        if (rc[(size_t)i] == HOST || rc[(size_t)i] == PENDING)
+            todo.push_back(i);
+        by_gpu += rc[(size_t)i] == WD_OK;
+    }
+    ctx->inflate_files_gpu += by_gpu;
+    ctx->inflate_files_host += (long long)todo.size();
+    if (!todo.empty()) {
+        std::atomic<size_t> next{0};
+        auto host = [&]() {
+            for (;;) {
+                const size_t k = next.fetch_add(1);
+                if (k >= todo.size())
+                    return;
+                const int i = todo[k];
+                rc[(size_t)i] = wd_load_cbcl_tile(ctx, paths[i], tile_number[i], filter_dev[i], n_clusters, dst_dev[i]);
+            }
+        };
+        std::vector<std::thread> hp;
+        for (int t = 0; t < threads && (size_t)t < todo.size(); t++)
+            hp.emplace_back(host);
+        for (auto &t : hp)
+            t.join();
+    }
+    int first = WD_OK;
+    for (int i = 0; i < n; i++) {
+        if (rc_out)
+            rc_out[i] = rc[(size_t)i];
+        if (first == WD_OK && rc[(size_t)i] != WD_OK)
+            first = rc[(size_t)i];
+    }
+    return first;
+}
+
 int wd_gather_wells(wd_ctx *ctx, const uint8_t *const *planes, int L, const int32_t *idx, int64_t n,
                     int64_t n_clusters, uint8_t *out_host)
 {

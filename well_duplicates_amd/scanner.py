@@ -282,6 +282,21 @@ class Scanner:
         if rc != _lib.OK:
             _raise(self._lib, None, rc, path)
 
+    def load_cbcl_batch(self, entries: Sequence, n_clusters: int, threads: int = 16):
+        """entries: [(cbcl path, tile number, filter pointer, plane pointer)] - the tiles' blocks are
+        inflated on the GPU in one launch and expanded (wd_load_cbcl_batch); the filters must be
+        loaded.  Raises what load_cbcl_tile raises for the first entry that fails."""
+        n = len(entries)
+        c_paths = (ctypes.c_char_p * max(1, n))(*[os.fsencode(e[0]) for e in entries])
+        c_tiles = (ctypes.c_int * max(1, n))(*[int(e[1]) for e in entries])
+        c_filt = (ctypes.c_void_p * max(1, n))(*[int(e[2]) for e in entries])
+        c_dst = (ctypes.c_void_p * max(1, n))(*[int(e[3]) for e in entries])
+        rcs = (ctypes.c_int * max(1, n))()
+        self._lib.wd_load_cbcl_batch(self._ctx, n, c_paths, c_tiles, c_filt, c_dst, int(n_clusters), int(threads), rcs)
+        for i in range(n):
+            if rcs[i] != _lib.OK:
+                _raise(self._lib, None, rcs[i], entries[i][0])
+
     def gather_wells(self, plane_ptrs: Sequence[int], idx, n_clusters: int) -> np.ndarray:
         """uint8 [len(idx), L]: bytes of the given wells over the L planes."""
         idx = np.ascontiguousarray(idx, dtype=np.int32)
