@@ -201,8 +201,93 @@ def novaseq_probe(device, n_tiles, levels=7, targets=10000, bases=50):
                  "algorithmic_bytes": b_alg,
                  "alg_bytes_over_peak": round(b_alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
                 "novaseq_%s_T%d_l%d_L%d" % (case, T, levels, bases), n_tiles, ms)
+        # the .cbcl side of this config: 8 tiles x `bases` cycles as NovaSeq writes them (one file per
+        # cycle and surface, one gzip block per tile: 2 wells per byte, 2 quality bits, excluded wells
+        # left out), through the GPU decoder (wd_load_cbcl_batch) and through the host loader
+        try:
+            res["cbcl_ingest"] = cbcl_ingest_probe(sc, tb, spec, [int(t) for t in tile_ids[:min(8, n_tiles)]], bases, n)
+        except Exception as e:          # noqa: BLE001 - a measurement, not the scan
+            res["cbcl_ingest"] = {"error": repr(e)}
         tb.free()
         return res
+
+
+def cbcl_ingest_probe(sc, tb, spec, tile_ids, cycles, n):
+    import gzip
+    import shutil
+    import struct
+    import tempfile
+    from concurrent.futures import ThreadPoolExecutor
+    import numpy as np
+    from well_duplicates_amd import synth
+    from well_duplicates_amd.scanner import TileBatch
+    threads = min(32, os.cpu_count() or 1)
+    root = tempfile.mkdtemp(prefix="wd_cbcl_")
+    try:
+        filters = {t: synth.filter_bytes(spec, 1, t) for t in tile_ids}
+        keep = {t: (filters[t] & 1) == 1 for t in tile_ids}
+        surfaces = sorted({str(t)[0] for t in tile_ids})
+        gz_total = [0]
+
+        def write(c):
+            for sf in surfaces:
+                mine = [t for t in tile_ids if str(t)[0] == sf]
+                blocks, table = [], b""
+                for t in mine:
+                    plane = tb.download_plane(tile_ids.index(t), c)
+                    nib = np.where(plane == 0, 0, (plane & 3) | (((plane >> 2) % 3 + 1) << 2)).astype(np.uint8)[keep[t]]
+                    cnt = nib.shape[0]
+                    if cnt % 2:
+                        nib = np.concatenate([nib, np.zeros(1, np.uint8)])
+                    packed = (nib[0::2] | (nib[1::2] << 4)).astype(np.uint8).tobytes()
+                    comp = gzip.compress(packed, compresslevel=6)
+                    blocks.append(comp)
+                    table += struct.pack("<IIII", t, cnt, len(packed), len(comp))
+                    gz_total[0] += len(comp)
+                head = struct.pack("<HIBBI", 1, 5681, 2, 2, 4) + b"".join(struct.pack("<II", i, i) for i in range(4))
+                head += struct.pack("<I", len(mine)) + table + b"\x01"
+                with open(os.path.join(root, "C%d_%s.cbcl" % (c, sf)), "wb") as fh:
+                    fh.write(head + b"\0" * (5681 - len(head)) + b"".join(blocks))
+        with ThreadPoolExecutor(max_workers=threads) as pool:
+            list(pool.map(write, range(cycles)))
+        out = TileBatch(sc, len(tile_ids), cycles, n)
+        for i, t in enumerate(tile_ids):
+            sc.h2d(out.filter_ptr(i), filters[t])
+        entries = [(os.path.join(root, "C%d_%s.cbcl" % (c, str(t)[0])), t, out.filter_ptr(i), out.plane_ptr(i, c))
+                   for i, t in enumerate(tile_ids) for c in range(cycles)]
+
+        def gpu():
+            t1 = time.perf_counter()
+            sc.load_cbcl_batch(entries, n, threads=threads)
+            return time.perf_counter() - t1
+
+        def host():
+            t1 = time.perf_counter()
+            with ThreadPoolExecutor(max_workers=threads) as pool:
+                list(pool.map(lambda e: sc.load_cbcl_tile(e[0], e[1], e[2], n, e[3]), entries))
+            return time.perf_counter() - t1
+        gpu()
+        g0 = sc.get_option("inflate_files_gpu")
+        gpu_s = min(gpu() for _ in range(3))
+        on_gpu = (sc.get_option("inflate_files_gpu") - g0) // 3
+        check = out.download_plane(len(tile_ids) - 1, cycles - 1)
+        host()
+        host_s = min(host() for _ in range(2))
+        same = bool((out.download_plane(len(tile_ids) - 1, cycles - 1) == check).all())
+        want = tb.download_plane(len(tile_ids) - 1, cycles - 1)
+        k = keep[tile_ids[-1]]
+        codes_ok = bool((np.where(check[k] == 0, 4, check[k] & 3) == np.where(want[k] == 0, 4, want[k] & 3)).all()
+                        and (check[~k] == 0).all())
+        plane_bytes = len(entries) * n
+        out.free()
+        return {"tiles": len(tile_ids), "blocks": len(entries), "decoded_on_gpu": int(on_gpu), "gz_bytes": gz_total[0],
+                "plane_bytes": plane_bytes, "gpu_inflate_seconds": round(gpu_s, 4),
+                "gpu_inflate_plane_gb_per_s": round(plane_bytes / gpu_s / 1e9, 2),
+                "gpu_kernel_ms_per_block": round(sc.get_option("inflate_us_per_file") / 1e3, 2),
+                "host_inflate_seconds": round(host_s, 4), "host_inflate_plane_gb_per_s": round(plane_bytes / host_s / 1e9, 2),
+                "threads": threads, "same_planes": same, "base_codes_as_generated": codes_ok}
+    finally:
+        shutil.rmtree(root, ignore_errors=True)
 
 
 def e2e_probe(device, n_tiles, rows, cols, centre, lvl_off, nbr, cycles=50, threads=None):

@@ -2731,6 +2731,9 @@ int wd_load_cbcl_batch(wd_ctx *ctx, int n, const char *const *paths, const int *
         // (a block shorter than the tile without excluded wells: the host path's IndexError)
         rc[(size_t)i] = good && (e.excluded || (long long)e.usize * 2 >= n_clusters) ? WD_OK : HOST;
         real_sum += r.t_real;
+        if (!good && getenv("WD_INFLATE_STATS"))
+            fprintf(stderr, "[wd inflate] block %d declined: status %u produced %u (table %u) end %u of %u crc %08x/%08x isize %u\n",
+                    i, r.status, r.produced, e.usize, r.end_byte, e.csize, r.crc, crc, isize);
     }
     if (!job_file.empty())
         ctx->inflate_us_per_file = (long long)(real_sum / 100 / job_file.size());
