@@ -402,7 +402,6 @@ def e2e_probe(device, n_tiles, rows, cols, centre, lvl_off, nbr, cycles=50, thre
                 "gpu_inflate_gain": round(host / best, 3) if best > 0 else None,
                 "ingest_only": ingest,
                 "interleaved_layout_seconds": round(inter, 4),
-                "interleaved_layout_note": "host inflate (the GPU decoder writes plain planes)",
                 "same_report": text == text_s == text_i == text_h, "run_dir_write_s": round(write_s, 1),
                 "reference_s_per_tile": 7.9,
                 "reference_note": "unmodified reference, 1 core, same geometry, --hamming -e 0 (BASELINE.md; measured in "

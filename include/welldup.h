@@ -223,9 +223,11 @@ int wd_load_bcl_gz_batch(wd_ctx *ctx, int n_files, const char *const *paths, uin
 /* The same with the tiles' .filter files in the batch: is_filter[i] != 0 marks file i as a .filter
  * (header 0, 3, n_clusters checked as wd_load_filter does, :148-152, :236-240; its n_clusters bytes are
  * copied, not decoded).  is_filter = NULL: wd_load_bcl_gz_batch.  One call then brings everything a
- * batch of tiles needs into HBM over one ring of pinned memory and two streams. */
+ * batch of tiles needs into HBM over one ring of pinned memory and two streams.
+ * well_stride = 4 lands every decoded plane in its byte lane of an interleaved group, as
+ * wd_load_bcl_gz_strided does (dst_dev[i] = group base + cycle % 4); filters are never strided. */
 int wd_load_tile_files_batch(wd_ctx *ctx, int n_files, const char *const *paths, uint8_t *const *dst_dev,
-                             const uint8_t *is_filter, int64_t n_clusters, int threads, int *rc);
+                             const uint8_t *is_filter, int64_t n_clusters, int well_stride, int threads, int *rc);
 /* Resident layout option for the equality / Hamming scan of sampled targets.  A line of HBM holds
  * 128 wells of ONE cycle in the BCL files' plane-per-cycle layout, and the scan wants ~11
  * neighbouring wells of SEVERAL cycles: with the cycles interleaved by four ([group of 4 cycles]

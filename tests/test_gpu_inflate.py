@@ -306,3 +306,32 @@ def test_cbcl_blocks_through_the_gpu_decoder(sc, tmp_path, excluded):
         sc.load_cbcl_batch([(str(bad), int(tiles[-1]), many.filter_ptr(2), many.plane_ptr(2, 1))], n)
     one.free()
     many.free()
+
+
+def test_interleaved_layout_through_the_gpu_decoder(sc, tmp_path):
+    """well_stride = 4: every plane decoded on the GPU lands in its byte lane of the group of four cycles
+    (what wd_load_bcl_gz_strided does on the host)."""
+    from well_duplicates_amd.scanner import TileBatch
+    n, cycles = 50003, 6
+    spec = synth.SynthSpec(seed=14, n_clusters=n, row=211, qual_levels=7)
+    tb = TileBatch(sc, 2, cycles, n, interleave=4)
+    paths, dsts, want = [], [], {}
+    for i, t in enumerate((1101, 1102)):
+        for c in range(cycles):
+            payload = synth.plane_bytes(spec, 1, t, c)
+            p = tmp_path / ("t%d_c%d.bcl.gz" % (t, c))
+            p.write_bytes(_bcl(payload))
+            paths.append(str(p))
+            dsts.append(tb.plane_ptr(i, c))
+            want[(i, c)] = payload
+    g0 = sc.get_option("inflate_files_gpu")
+    sc.load_bcl_gz_batch(paths, dsts, n, threads=3, well_stride=4)
+    assert sc.get_option("inflate_files_gpu") - g0 == len(paths)
+    for (i, c), payload in want.items():
+        assert (tb.download_plane(i, c) == payload).all(), (i, c)
+    # a file the decoder declines takes the host path into the same lane
+    z = tmp_path / "zeros.bcl.gz"
+    z.write_bytes(_bcl(np.zeros(n, np.uint8)))
+    sc.load_bcl_gz_batch([str(z)], [tb.plane_ptr(1, 3)], n, well_stride=4)
+    assert (tb.download_plane(1, 3) == 0).all() and (tb.download_plane(1, 2) == want[(1, 2)]).all()
+    tb.free()

@@ -74,7 +74,7 @@ PROTOTYPES = {
     "wd_load_filter": (_i, [_vp, ctypes.c_char_p, _vp, _i64]),
     "wd_load_bcl_gz_batch": (_i, [_vp, _i, ctypes.POINTER(ctypes.c_char_p), _pp, _i64, _i, ctypes.POINTER(_i)]),
     "wd_load_tile_files_batch": (_i, [_vp, _i, ctypes.POINTER(ctypes.c_char_p), _pp, ctypes.POINTER(ctypes.c_uint8), _i64,
-                                      _i, ctypes.POINTER(_i)]),
+                                      _i, _i, ctypes.POINTER(_i)]),
     "wd_load_cbcl_tile": (_i, [_vp, ctypes.c_char_p, _i, _vp, _i64, _vp]),
     "wd_load_cbcl_batch": (_i, [_vp, _i, ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(_i), _pp, _pp, _i64, _i,
                                 ctypes.POINTER(_i)]),

@@ -188,10 +188,10 @@ def scan_lane(sc: Scanner, reader, lane, tiles, cycle_list, mode, k, csr, wells,
         # GPU (wd_load_cbcl_tile), which needs the tile's filter first.
         jobs = [(i, c) for i in range(len(handles)) for c in range(len(cycle_list))]
         batch = None                        # which files the GPU decoder gets as one batch
-        if gpu_inflate and interleave == 1 and jobs:
+        if gpu_inflate and jobs:
             if os.path.exists(handles[0].plane_path(cycle_list[0])):
                 batch = "bcl.gz"
-            elif os.path.exists(handles[0].cbcl_path(cycle_list[0])):
+            elif interleave == 1 and os.path.exists(handles[0].cbcl_path(cycle_list[0])):
                 batch = "cbcl"
         # (in a batch the filters travel with the planes, below)
         filt = [] if batch else [pool.submit(sc.load_filter, h.filter_file, tb.filter_ptr(i), n_clusters)
@@ -222,7 +222,7 @@ def scan_lane(sc: Scanner, reader, lane, tiles, cycle_list, mode, k, csr, wells,
             def load_all():
                 missing = sc.load_bcl_gz_batch([handles[i].plane_path(cycle_list[c]) for i, c in jobs],
                                                [tb.plane_ptr(i, c) for i, c in jobs], n_clusters,
-                                               threads=max(1, threads), missing_ok=True,
+                                               threads=max(1, threads), missing_ok=True, well_stride=interleave,
                                                filters=[(h.filter_file, tb.filter_ptr(i)) for i, h in enumerate(handles)])
                 for j in missing:           # (a run is .bcl.gz or .cbcl, never both: this loop is for the odd file)
                     load(*jobs[j])

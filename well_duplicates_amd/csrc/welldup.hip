@@ -1996,12 +1996,14 @@ int inflate_prepare(wd_ctx *ctx, wd_ctx::InflateSlot &sl, int n_chunks, size_t a
 int wd_load_bcl_gz_batch(wd_ctx *ctx, int n_files, const char *const *paths, uint8_t *const *dst_dev,
                          int64_t n_clusters, int threads, int *rc_out)
 {
-    return wd_load_tile_files_batch(ctx, n_files, paths, dst_dev, nullptr, n_clusters, threads, rc_out);
+    return wd_load_tile_files_batch(ctx, n_files, paths, dst_dev, nullptr, n_clusters, 1, threads, rc_out);
 }
 
 int wd_load_tile_files_batch(wd_ctx *ctx, int n_files, const char *const *paths, uint8_t *const *dst_dev,
-                             const uint8_t *is_filter, int64_t n_clusters, int threads, int *rc_out)
+                             const uint8_t *is_filter, int64_t n_clusters, int well_stride, int threads, int *rc_out)
 {
+    if (well_stride != 1 && well_stride != 4)
+        return WD_ERR_ARG;
     if (!ctx || n_files < 0 || (n_files && (!paths || !dst_dev)) || n_clusters < 0 || n_clusters > 0x7FFFFFF0ll)
         return WD_ERR_ARG;
     if (hipSetDevice(ctx->device) != hipSuccess)
@@ -2026,7 +2028,7 @@ int wd_load_tile_files_batch(wd_ctx *ctx, int n_files, const char *const *paths,
     // sizes, then groups of consecutive files that fit a chunk
     for (int i = 0; i < n_files; i++) {
         struct stat st;
-        if (!paths[i] || !dst_dev[i] || ((uintptr_t)dst_dev[i] & 3)) {
+        if (!paths[i] || !dst_dev[i] || (((uintptr_t)dst_dev[i] & 3) && (well_stride == 1 || (is_filter && is_filter[i])))) {
             rc[(size_t)i] = WD_ERR_ARG;
         } else if (stat(paths[i], &st) != 0 || !S_ISREG(st.st_mode)) {
             rc[(size_t)i] = WD_ERR_IO;                                   // FileNotFoundError in the reference
@@ -2052,7 +2054,10 @@ int wd_load_tile_files_batch(wd_ctx *ctx, int n_files, const char *const *paths,
     }
     const int n_groups = (int)groups.size();
     if (n_groups) {
-        const int prc = inflate_prepare(ctx, slot, std::min(n_groups, kChunks), arena_bytes, n_jobs);
+        // (interleaved layout: the planes are decoded into the arena and scattered into their byte lanes)
+        const size_t plane_room = well_stride == 4 ? (((size_t)n_clusters + 8 + 255) & ~(size_t)255) : 0;
+        const int prc = inflate_prepare(ctx, slot, std::min(n_groups, kChunks),
+                                        ((arena_bytes + 255) & ~(size_t)255) + plane_room * n_jobs, n_jobs);
         if (prc)
             return prc;
         // (the batch before may still be decoding; its chunk copies are behind us after this)
@@ -2141,7 +2146,9 @@ int wd_load_tile_files_batch(wd_ctx *ctx, int n_files, const char *const *paths,
             }
             InfJob &j = slot.h_jobs[job_file.size()];
             j.file = reinterpret_cast<const uint32_t *>(dev + offset[(size_t)i]);
-            j.obase = dst_dev[i] - 4;
+            j.obase = well_stride == 4 ? slot.arena + ((arena_bytes + 255) & ~(size_t)255) +
+                                             ((((size_t)n_clusters + 8 + 255) & ~(size_t)255) * job_file.size())
+                                       : dst_dev[i] - 4;
             j.file_bytes = (uint32_t)size[(size_t)i];
             j.stream_off = stream_off[(size_t)i];
             j.out_cap = (uint32_t)(n_clusters + 4);
@@ -2184,8 +2191,12 @@ int wd_load_tile_files_batch(wd_ctx *ctx, int n_files, const char *const *paths,
                 hipLaunchKernelGGL((k_inflate<4, 256>), dim3(nj), dim3(256), 0, stream, slot.d_jobs + j0, slot.d_res + j0);
             else
                 hipLaunchKernelGGL((k_inflate<1, 512>), dim3(nj), dim3(64), 0, stream, slot.d_jobs + j0, slot.d_res + j0);
-            hipLaunchKernelGGL(k_inflate_crc, dim3(nj), dim3(256), 0, stream, slot.d_jobs + j0,
-                                   slot.d_res + j0);
+            hipLaunchKernelGGL(k_inflate_crc, dim3(nj), dim3(256), 0, stream, slot.d_jobs + j0, slot.d_res + j0);
+            if (well_stride == 4 && n_clusters > 0)
+                for (unsigned q = 0; q < nj; q++)
+                    hipLaunchKernelGGL(k_scatter_plane4, dim3((unsigned)((n_clusters + 4ll * kBlock - 1) / (4ll * kBlock))),
+                                       dim3(kBlock), 0, stream, slot.h_jobs[j0 + q].obase + 4, (long long)n_clusters,
+                                       dst_dev[job_file[j0 + q]]);
                 if (hipGetLastError() != hipSuccess ||
                     hipMemcpyAsync(slot.h_res + j0, slot.d_res + j0, sizeof(InfResult) * nj,
                                    hipMemcpyDeviceToHost, stream) != hipSuccess) {
@@ -2284,7 +2295,7 @@ int wd_load_tile_files_batch(wd_ctx *ctx, int n_files, const char *const *paths,
                     return;
                 const int i = todo[k];
                 rc[(size_t)i] = is_filter && is_filter[i] ? wd_load_filter(ctx, paths[i], dst_dev[i], n_clusters)
-                                                          : wd_load_bcl_gz_strided(ctx, paths[i], dst_dev[i], n_clusters, 1);
+                                                          : wd_load_bcl_gz_strided(ctx, paths[i], dst_dev[i], n_clusters, well_stride);
             }
         };
         std::vector<std::thread> hp;

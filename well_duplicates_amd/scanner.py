@@ -244,7 +244,7 @@ class Scanner:
             _raise(self._lib, None, rc, path)
 
     def load_bcl_gz_batch(self, paths: Sequence[str], dsts: Sequence[int], n_clusters: int, threads: int = 16,
-                          missing_ok: bool = False, filters: Sequence = ()):
+                          missing_ok: bool = False, filters: Sequence = (), well_stride: int = 1):
         """Many .bcl.gz files -> device planes, inflated on the GPU (wd_load_bcl_gz_batch: host threads
         only read the compressed files; one wave per file decodes).  Raises what load_bcl_gz raises
         for the first file that fails; with missing_ok the files that do not exist are returned
@@ -259,7 +259,8 @@ class Scanner:
         c_dsts = (ctypes.c_void_p * max(1, n))(*[int(d) for d in dsts])
         kinds = (ctypes.c_uint8 * max(1, n))(*([0] * n_gz + [1] * (n - n_gz)))
         rcs = (ctypes.c_int * max(1, n))()
-        self._lib.wd_load_tile_files_batch(self._ctx, n, c_paths, c_dsts, kinds, int(n_clusters), int(threads), rcs)
+        self._lib.wd_load_tile_files_batch(self._ctx, n, c_paths, c_dsts, kinds, int(n_clusters), int(well_stride),
+                                           int(threads), rcs)
         missing = []
         for i in range(n):
             if rcs[i] == _lib.OK:
