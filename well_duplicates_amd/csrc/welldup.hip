@@ -241,8 +241,9 @@ struct wd_ctx {
         hipEvent_t copied = nullptr;                   // the chunk's H2D copy is done: it may be refilled
     };
     static constexpr int kInflateChunks = 4;
-    // The files are decoded in launches of kInflateLaunchFiles (what the chip holds at once: 3
-    // workgroups per CU) or whatever the batch has, all on ONE stream: a wave's time per file does not
+    // The files are decoded in launches of kInflateLaunchFiles (two rounds of what the chip holds at
+    // four waves per file; launches of 512 were no faster on 1600 files and slower on 800: a large
+    // batch is bound by reading its files) or whatever the batch has, all on ONE stream: a wave's time per file does not
     // depend on how many files a launch holds, launches that share a hardware queue run one after the
     // other anyway (HIP multiplexes its streams onto ~4 of them; 4 launches on 4 streams took 3 kernel
     // times), and with a second stream for the chunk copies the next launch's files arrive while this
