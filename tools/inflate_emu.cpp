@@ -62,6 +62,7 @@ inline uint32_t wv_shfl_up(uint32_t v, int d)
     return r;
 }
 inline uint32_t wv_uniform(uint32_t v) { return wv_shfl(v, 0); }
+inline uint32_t wv_readlane(uint32_t v, uint32_t src) { return wv_shfl(v, (int)src); }
 inline void wv_sync() { bar(); }
 inline uint32_t wv_hist_byte(const uint8_t *p) { return *p; }
 inline void wv_stores_done() {}
