@@ -85,3 +85,78 @@ def test_integration_stub_rebuilds_lane_dupl(tmp_path):
                     assert got == want, (run["flags"], lane, tile)
     finally:
         _wd.wd_destroy(ctx)
+
+
+def test_integration_stub_batch_ingest(tmp_path):
+    """The second stub of INTEGRATION.md ("the gunzip loop on the GPU"), as written: planes and filters
+    of a batch of tiles through wd_load_tile_files_batch into device memory, wd_count_tiles on the device
+    pointers - the reference's lane_dupl again."""
+    fx = load_fixture("mid")
+    spec = synth.spec_from_dict(fx["spec"])
+    all_cycles = sorted({c for run in fx["runs"] for a, b in run["cycles"] for c in range(a, b)})
+    synth.write_run_dir(spec, str(tmp_path), fx["lanes"], fx["tiles"], all_cycles)
+    _wd = ctypes.CDLL(_lib.LIB_PATH)
+    _wd.wd_create.restype = ctypes.c_void_p
+    _wd.wd_create.argtypes = [ctypes.c_int]
+    _wd.wd_destroy.argtypes = [ctypes.c_void_p]
+    _wd.wd_strerror.restype = ctypes.c_char_p
+    _wd.wd_malloc.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.POINTER(ctypes.c_void_p)]
+    _wd.wd_free.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+    _wd.wd_set_targets.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int] + [ctypes.c_void_p] * 3
+    _wd.wd_count_tiles.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                   ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_void_p),
+                                   ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p]
+    _wd.wd_load_tile_files_batch.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(ctypes.c_char_p),
+                                             ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_uint8), ctypes.c_int64,
+                                             ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_int)]
+
+    def _ck(rc):
+        if rc:
+            raise RuntimeError(_wd.wd_strerror(rc).decode())
+
+    level = fx["levels"]
+    targets = load_targets(os.path.join(GOLD, fx["targets_file"]), levels=level + 1, limit=fx["n_targets"])
+    ctx = _wd.wd_create(0)
+    assert ctx
+    try:
+        centre, lvl_off, nbr = targets.to_csr(level)
+        lens = np.diff(lvl_off.astype(np.int64), axis=1)
+        _ck(_wd.wd_set_targets(ctx, len(centre), level, centre.ctypes.data, lvl_off.ctypes.data, nbr.ctypes.data))
+        bcl_reader = bcl.BCLReader(str(tmp_path))
+        run = next(r for r in fx["runs"] if not r.get("exception"))
+        mode, k, cycles = {"eq": 0, "hamming": 1, "levenshtein": 2}[run["mode"]], run["k"], run["cycles"]
+        for lane_rec in run["lanes"]:
+            batch = [bcl_reader.get_tile(lane_rec["lane"], t) for t in lane_rec["lane_dupl"]]
+            # --- as in INTEGRATION.md ---------------------------------------------------------
+            n, L = batch[0].num_clusters, sum(e - s for s, e in cycles)
+            stride = (n + 255) // 256 * 256
+            dev = ctypes.c_void_p()
+            _ck(_wd.wd_malloc(ctx, stride * (L + 1) * len(batch), ctypes.byref(dev)))
+            paths, dsts, kinds = [], [], []
+            for i, t in enumerate(batch):
+                base = dev.value + i * stride * (L + 1)
+                for j, cyc in enumerate(c for s, e in cycles for c in range(s, e)):
+                    paths.append(os.path.join(t.data_dir, "C%i.1" % (cyc + 1), t.bcl_filename).encode())
+                    dsts.append(base + j * stride)
+                    kinds.append(0)
+                paths.append(t.filter_file.encode())
+                dsts.append(base + L * stride)
+                kinds.append(1)
+            rc = (ctypes.c_int * len(paths))()
+            _ck(_wd.wd_load_tile_files_batch(ctx, len(paths), (ctypes.c_char_p * len(paths))(*paths),
+                                             (ctypes.c_void_p * len(paths))(*dsts), (ctypes.c_uint8 * len(paths))(*kinds),
+                                             n, 1, 16, rc))
+            # --- the scan on the device pointers --------------------------------------------
+            ptrs = (ctypes.c_void_p * (L * len(batch)))(*[dev.value + i * stride * (L + 1) + j * stride
+                                                          for i in range(len(batch)) for j in range(L)])
+            fptr = (ctypes.c_void_p * len(batch))(*[dev.value + i * stride * (L + 1) + L * stride for i in range(len(batch))])
+            block = np.zeros((len(batch), 1 + 5 * level), dtype=np.int64)
+            per_target = np.zeros((len(batch), len(centre), level), dtype=np.uint32)
+            _ck(_wd.wd_count_tiles(ctx, len(batch), L, mode, k, ptrs, fptr, n, block.ctypes.data, per_target.ctypes.data))
+            for i, (tile, want) in enumerate(lane_rec["lane_dupl"].items()):
+                got = [[[int(per_target[i, t, l]), int(lens[t, l])] for l in range(level)]
+                       for t in range(len(centre)) if per_target[i, t, 0] != 0xFFFFFFFF]
+                assert got == want, (run["flags"], tile)
+            _ck(_wd.wd_free(ctx, dev))
+    finally:
+        _wd.wd_destroy(ctx)
