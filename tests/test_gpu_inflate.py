@@ -151,12 +151,15 @@ def test_batch_reports_what_the_reference_raises(sc, tmp_path):
         "short": (gzip.compress(raw[:-10]), IndexError),                          # fails at slurped_file[idx] in the reference
         "count": (gzip.compress(synth.bcl_file_bytes(payload[:-1]) + b"\0"), AssertionError),   # header != clusters (:338)
         "long": (gzip.compress(raw + b"\1" * 100), payload),                        # extra bytes after the plane are never indexed
+        # ... but the reference reads them all, so a bad CRC behind an overlong stream is still an error
+        "longbadcrc": ((lambda z: z[:-6] + bytes([z[-6] ^ 1]) + z[-5:])(gzip.compress(raw + b"\1" * 200000)),
+                       (zlib.error, gzip.BadGzipFile)),
     }
     # every one of these must agree with what Python's gzip says about the same bytes
     for name, (data, want) in files.items():
         if isinstance(want, np.ndarray):
             assert gzip.decompress(data)[4:4 + n] == want.tobytes(), name
-        elif want in (EOFError, gzip.BadGzipFile) or name in ("damaged", "badcrc"):
+        elif want in (EOFError, gzip.BadGzipFile) or name in ("damaged", "badcrc", "longbadcrc"):
             with pytest.raises((EOFError, gzip.BadGzipFile, zlib.error)):
                 gzip.decompress(data)
     _load_and_check(sc, tmp_path, files, n)

@@ -1879,11 +1879,19 @@ int wd_load_bcl_gz_strided(wd_ctx *ctx, const char *path, uint8_t *dst_dev, int6
         zs.avail_in = (uInt)std::min<size_t>(raw_len, 0xFFFFFFFFu);
         produced = 0;
         bad = raw_len > 0xFFFFFFFFu;
+        // (the reference reads the whole file, so a stream that decodes to more than a plane is still
+        // decoded to its end - into a scratch buffer - for its CRC and end marker to be checked)
+        std::vector<uint8_t> spill;
         while (!bad) {
-            zs.next_out = lease.slot->pinned + produced;
-            zs.avail_out = (uInt)std::min<size_t>(want + 64 - produced, 0x7FFFFFFFu);
+            const bool full = produced >= want + 64;
+            if (full && spill.empty())
+                spill.resize(1u << 16);
+            zs.next_out = full ? spill.data() : lease.slot->pinned + produced;
+            zs.avail_out = full ? (uInt)spill.size() : (uInt)std::min<size_t>(want + 64 - produced, 0x7FFFFFFFu);
+            const uInt in_before = zs.avail_in, out_before = zs.avail_out;
             const int zr = inflate(&zs, Z_NO_FLUSH);
-            produced = (size_t)(zs.next_out - lease.slot->pinned);
+            if (!full)
+                produced = (size_t)(zs.next_out - lease.slot->pinned);
             if (zr == Z_STREAM_END) {
                 if (zs.avail_in == 0)
                     break;
@@ -1891,12 +1899,20 @@ int wd_load_bcl_gz_strided(wd_ctx *ctx, const char *path, uint8_t *dst_dev, int6
                     bad = true;
                 continue;
             }
-            if (zr != Z_OK || zs.avail_out == 0) {
-                bad = zr != Z_OK;                          // avail_out == 0: more data than a plane
+            if (zr == Z_BUF_ERROR && zs.avail_in == 0) {
+                truncated = true;                          // nothing left to read and no end marker seen
                 break;
             }
-            if (zs.avail_in == 0) {
+            if (zr != Z_OK && !(zr == Z_BUF_ERROR && zs.avail_out == 0)) {
+                bad = true;
+                break;
+            }
+            if (zs.avail_in == 0 && zs.avail_out != 0) {
                 truncated = true;                          // the stream ends before its end marker
+                break;
+            }
+            if (zs.avail_in == in_before && zs.avail_out == out_before) {
+                bad = true;                                // no progress: cannot happen with room and input at hand
                 break;
             }
         }
