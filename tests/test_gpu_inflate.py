@@ -120,8 +120,12 @@ def test_batch_decoded_on_the_gpu_at_full_size(sc, tmp_path):
             spec = synth.SynthSpec(seed=21, n_clusters=n, row=1571, qual_levels=q)
             payload = synth.plane_bytes(spec, 2, 1205, c)
             files["c%d" % c] = (_bcl(payload, 6 if c % 2 else 1), payload)
+        # two values in turn: every match (258 bytes at distance 2) copies from the one before it - 16 700
+        # deep, past the decoder's turn budget: the host takes the file, the rest stay on the GPU
+        ab = np.tile(np.array([7, 9], np.uint8), n // 2 + 1)[:n]
+        files["chain"] = (_bcl(ab, 6), ab)
         by_gpu, by_host = _load_and_check(sc, tmp_path, files, n, threads=3)
-        assert (by_gpu, by_host) == (len(files), 0)
+        assert (by_gpu, by_host) == (len(files) - 1, 1)
     finally:
         sc.set_option("inflate_chunk_mb", 16)
 
