@@ -342,3 +342,32 @@ def test_interleaved_layout_through_the_gpu_decoder(sc, tmp_path):
     sc.load_bcl_gz_batch([str(z)], [tb.plane_ptr(1, 3)], n, well_stride=4)
     assert (tb.download_plane(1, 3) == 0).all() and (tb.download_plane(1, 2) == want[(1, 2)]).all()
     tb.free()
+
+
+def test_batches_from_several_threads(sc, tmp_path):
+    """Three callers at once on one context (the CLI keeps two batches in flight): the calls share the
+    pinned ring and the streams, alternate between two arenas, and every plane must be the right one."""
+    from concurrent.futures import ThreadPoolExecutor
+    n, per = 120001, 9
+    stride = (n + 255) // 256 * 256
+    buf = sc.malloc(3 * per * stride + 256)
+    sets = []
+    for t in range(3):
+        spec = synth.SynthSpec(seed=30 + t, n_clusters=n, row=400, qual_levels=7)
+        paths, dsts, want = [], [], []
+        for c in range(per):
+            payload = synth.plane_bytes(spec, 1, 1101 + t, c)
+            p = tmp_path / ("s%d_c%d.bcl.gz" % (t, c))
+            p.write_bytes(_bcl(payload, 1 if c % 2 else 6))
+            paths.append(str(p))
+            dsts.append(buf + (t * per + c) * stride)
+            want.append(payload)
+        sets.append((paths, dsts, want))
+    for rep in range(3):
+        sc.memset(buf, 0, 3 * per * stride)
+        with ThreadPoolExecutor(max_workers=3) as pool:
+            list(pool.map(lambda s: sc.load_bcl_gz_batch(s[0], s[1], n, threads=2), sets))
+        for paths, dsts, want in sets:
+            for d, w in zip(dsts, want):
+                assert (sc.d2h(d, n) == w).all()
+    sc.free(buf)
