@@ -1969,6 +1969,10 @@ int inflate_prepare(wd_ctx *ctx, wd_ctx::InflateSlot &sl, int n_chunks, size_t a
     if (!sl.done && hipEventCreateWithFlags(&sl.done, hipEventDisableTiming) != hipSuccess)
         return WD_ERR_HIP;
     if (ctx->inflate_chunk_cap != ctx->inflate_chunk_bytes) {            // the option changed: new buffers
+        // (the batch before may still be copying out of the old ones)
+        if (ctx->inflate_streams[wd_ctx::kInflateStreams] &&
+            hipStreamSynchronize(ctx->inflate_streams[wd_ctx::kInflateStreams]) != hipSuccess)
+            return WD_ERR_HIP;
         for (auto &ch : ctx->inflate_chunks) {
             (void)hipHostFree(ch.pinned);
             ch.pinned = nullptr;
