@@ -517,19 +517,18 @@ void launch_queue_lev(wd_ctx *ctx, const ScanArgs &a, dim3 grid)
             return;
         }
     }
-    // an odd threshold (k = 2H + 1) keeps random neighbours alive about one cycle longer
     // The first round (every neighbour, lane per slot) is shorter than the sequential kernel's: since
     // the survivors are drained in rounds of 1, 2, 4, 8 cycles, what the first round leaves alive is
     // cheap, and every cycle it reads costs a line per row segment.  Measured for H = 1 on the bench
     // workload (k = 2): 7 cycles 0.317 ms, 6: 0.291, 5: 0.280, 4: 0.303, 3: 0.349.
-    // (Wider bands - k = 4..7 - gain nothing from a shorter first round: 10 - 2 cycles 0.453 ms against
-    // 0.484 at k = 4, but 0.550 against 0.542 at k = 5, and worse beyond.)
-    constexpr int first = lev_first(H) - (H == 1 ? 2 : 0);
+    // (Wider bands: 10 - 2 cycles 0.453 ms against 0.484 at k = 4, but 0.550 against 0.542 at k = 5, and
+    // worse beyond - only k = 4 takes the shorter round.)
+    constexpr int first_even = lev_first(H) - (H <= 2 ? 2 : 0), first_odd = lev_first(H) + 1 - (H == 1 ? 2 : 0);
     // an odd threshold (k = 2H + 1) keeps random neighbours alive about one cycle longer
     if (a.k & 1)
-        hipLaunchKernelGGL((k_scan_q<STRIDED, first + 1, H>), grid, dim3(kBlock), lds, ctx->stream, a);
+        hipLaunchKernelGGL((k_scan_q<STRIDED, first_odd, H>), grid, dim3(kBlock), lds, ctx->stream, a);
     else
-        hipLaunchKernelGGL((k_scan_q<STRIDED, first, H>), grid, dim3(kBlock), lds, ctx->stream, a);
+        hipLaunchKernelGGL((k_scan_q<STRIDED, first_even, H>), grid, dim3(kBlock), lds, ctx->stream, a);
 }
 
 // grow-only device scratch of the dense path
