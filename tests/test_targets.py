@@ -124,3 +124,71 @@ def test_limit_and_levels_like_cli():
     assert len(t) == 5 and t.levels == 3
     ref = oracle.py_load_targets(TEST_FILE, levels=3, limit=5)
     assert [c[0][0] for c in ref] == [x.get_centre() for x in t]
+
+
+# ---- the CLI's bulk parser: the same arrays as load_targets(...).to_csr(), or a refusal -----------
+def _write(tmp_path, name, text):
+    p = tmp_path / name
+    p.write_text(text)
+    return str(p)
+
+
+def _regular(rng, n_targets, n_lines, newline_at_end=True):
+    centres = rng.choice(10 ** 6, n_targets, replace=False)
+    recs = []
+    for c in centres:
+        recs.append(str(int(c)))
+        for _ in range(n_lines - 1):
+            recs.append(",".join(str(int(v)) for v in rng.integers(0, 4_000_000, int(rng.integers(2, 40)))))
+    return "\n".join(recs) + ("\n" if newline_at_end else "")
+
+
+def test_bulk_parser_equals_object_model(tmp_path):
+    import glob
+    import numpy as np
+    from helpers import GOLD
+    from well_duplicates_amd.targets import load_targets, load_targets_csr
+    rng = np.random.default_rng(4)
+    files = sorted(glob.glob(os.path.join(GOLD, "*.list")))
+    for k in range(6):
+        files.append(_write(tmp_path, "r%d.list" % k, _regular(rng, int(rng.integers(1, 60)), int(rng.integers(2, 8)), k % 2 == 0)))
+    seen_fast = 0
+    for f in files:
+        for level in (1, 2, 3, 5):
+            for limit in (None, 1, 7, 10 ** 6):
+                fast = load_targets_csr(f, level, limit)
+                try:
+                    t = load_targets(f, levels=level + 1, limit=limit)
+                    want = (len(t),) + t.to_csr(level)
+                except (AssertionError, ValueError):
+                    want = None
+                if fast is None:
+                    continue                                     # the CLI takes load_targets() then
+                assert want is not None, (f, level, limit)       # never an answer where the reference's parser fails
+                seen_fast += 1
+                assert fast[0] == want[0]
+                for a, b in zip(fast[1:], want[1:]):
+                    assert a.dtype == b.dtype and a.shape == b.shape and (a == b).all(), (f, level, limit)
+    assert seen_fast > 60
+
+
+def test_bulk_parser_refuses_what_is_not_regular(tmp_path):
+    import numpy as np
+    from well_duplicates_amd.targets import load_targets_csr
+    rng = np.random.default_rng(5)
+    good = _regular(rng, 5, 4)
+    assert load_targets_csr(_write(tmp_path, "good.list", good), 3) is not None
+    lines = good.split("\n")
+    for name, text in {
+        "blank_end": good + "\n",                                    # a trailing blank line (int('') in the reference)
+        "blank_mid": "\n".join(lines[:5] + [""] + lines[5:]),
+        "short_last": "\n".join(lines[:-2]) + "\n",                  # last record short of a line
+        "word": good.replace(lines[1].split(",")[0], "x7", 1),
+        "spaces": good.replace(",", ", ", 3),
+        "dup_centre": good + lines[0] + "\n" + "\n".join(lines[1:4]) + "\n",
+        "huge": good.replace(lines[2].split(",")[1], str(2 ** 31), 1),
+        "too_few_rings": good,                                       # asked for more rings than the file holds
+        "empty": "",
+    }.items():
+        level = 4 if name == "too_few_rings" else 3
+        assert load_targets_csr(_write(tmp_path, name + ".list", text), level) is None, name

@@ -36,7 +36,7 @@ from . import bcl as bcl_direct_reader
 from . import report, workload
 from .report import LENGTH, TALLY, output_writer  # noqa: F401  (reference module surface)
 from .scanner import INVALID_TARGET, Scanner, TileBatch, compare_mode
-from .targets import load_targets
+from .targets import load_targets, load_targets_csr
 
 __VERSION__ = 0.3        # report format version of the reference this mirrors (:4)
 
@@ -313,8 +313,14 @@ def main(argv=None):
         targets = csr = None
         wells = np.zeros(0, dtype=np.int64)
     else:
-        targets = load_targets(filename=args.coord_file, levels=args.level + 1, limit=args.sample_size)
-        csr = targets.to_csr(args.level)
+        # a regular targets file is parsed in bulk; anything else goes through the reference's parser,
+        # which raises what the reference raises
+        fast = load_targets_csr(args.coord_file, args.level, args.sample_size)
+        if fast is not None:
+            targets, n_parsed, csr = None, fast[0], fast[1:]
+        else:
+            targets = load_targets(filename=args.coord_file, levels=args.level + 1, limit=args.sample_size)
+            n_parsed, csr = len(targets), targets.to_csr(args.level)
         # every well some target touches = targets.get_all_indices(), sorted (the rings loaded are 1..-l)
         wells = np.unique(np.concatenate([csr[0], csr[2]]).astype(np.int64))
     reader = bcl_direct_reader.BCLReader(args.run)
@@ -341,7 +347,7 @@ def main(argv=None):
                 # the scan needs nothing of the rings on the host; the log of single duplicates is off
                 csr = (np.zeros(0, np.int32), np.zeros((0, levels + 1), np.int32), np.zeros(0, np.int32))
             else:
-                n_targets = len(targets)
+                n_targets = n_parsed
                 sc.set_targets(*csr)
             _lap("context, targets on the GPU")
             # (lane, tile) items are independent (count_well_duplicates.py:207-226): the flat list

@@ -156,3 +156,58 @@ def load_targets(filename, levels=None, limit=None):
             pending = []
         pending.append(ln)
     return all_targets
+
+
+def load_targets_csr(filename, level, limit=None):
+    """The scan path's view of a targets file without the object model: (number of targets,
+    centre[T], lvl_off[T, level+1], nbr[P]) exactly as `load_targets(filename, level + 1,
+    limit).to_csr(level)` gives them, parsed in bulk (numpy) - or None whenever the file is not
+    perfectly regular (a line that is not comma-separated integers, records of different lengths,
+    fewer rings than asked for, a repeated centre, values beyond int32, trailing blanks): the caller
+    then takes load_targets(), which raises what the reference raises (target.py:6-40, :72-78)."""
+    with open(filename, "r") as fh:
+        text = fh.read()
+    if not text or "\r" in text or " " in text or "\t" in text:
+        return None
+    lines = text.split("\n")
+    if lines[-1] == "":
+        lines.pop()                         # the last line's own newline
+    if not lines or "" in lines:
+        return None
+    commas = np.fromiter((ln.count(",") for ln in lines), dtype=np.int64, count=len(lines))
+    starts = np.flatnonzero(commas == 0)    # a line without a comma starts a record (target.py:27)
+    if starts.size == 0 or starts[0] != 0:
+        return None
+    per = int(starts[1]) if starts.size > 1 else len(lines)
+    if per < level + 1 or len(lines) % per or not np.array_equal(starts, np.arange(0, len(lines), per)):
+        return None
+    import warnings
+    try:
+        with warnings.catch_warnings():     # (numpy warns when it stops at something that is not a number)
+            warnings.simplefilter("ignore")
+            flat = np.fromstring(text.replace("\n", ","), dtype=np.int64, sep=",")
+    except ValueError:
+        return None
+    if flat.size != int(commas.sum()) + len(lines):
+        return None                         # something that is not an integer stopped the parse
+    if flat.size and (flat.min() < -(2 ** 31) or flat.max() >= 2 ** 31):
+        return None
+    n_rec = len(lines) // per
+    T = min(n_rec, int(limit)) if limit else n_rec
+    line_len = (commas + 1).reshape(n_rec, per)[:T]
+    line_off = np.concatenate([[0], np.cumsum(commas + 1)])[:-1].reshape(n_rec, per)[:T]
+    centre = flat[line_off[:, 0]]
+    if np.unique(centre).size != T:
+        return None                         # a centre twice: load_targets asserts (target.py:72)
+    ring_len = line_len[:, 1:level + 1]
+    lvl_off = np.zeros((T, level + 1), dtype=np.int64)
+    lvl_off[:, 1:] = np.cumsum(ring_len, axis=1)
+    lvl_off += np.concatenate([[0], np.cumsum(ring_len.sum(axis=1))[:-1]])[:, None]
+    if lvl_off.size and lvl_off[-1, -1] >= 2 ** 31:
+        return None
+    # the kept lines of every record are contiguous in `flat`: lines 1..level of record t
+    first = line_off[:, 1]
+    total = ring_len.sum(axis=1)
+    idx = np.repeat(first - np.concatenate([[0], np.cumsum(total)[:-1]]), total) + np.arange(int(total.sum()))
+    nbr = flat[idx]
+    return T, centre.astype(np.int32), lvl_off.astype(np.int32), nbr.astype(np.int32)
