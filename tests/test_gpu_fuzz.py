@@ -84,7 +84,7 @@ def test_fuzz(seed):
                         "dense_kernel": int(rng.choice([-1, 0, 1])) if trial else -1,
                         "dense_pack": int(rng.choice([-1, 0, 1])) if trial else -1,
                         "early_exit": int(rng.integers(0, 2)) if trial == 2 else 1,
-                        "queue_first": int(rng.choice([0, 1, 2, 3, 4, 6, 8]))}
+                        "queue_first": int(rng.choice([0, 1, 2, 3, 4, 5, 6, 7, 8]))}
                 for name, v in opts.items():
                     sc.set_option(name, v)
                 try:

@@ -179,7 +179,7 @@ def test_kernel_variants_agree(sc):
         base[(mode, k)] = tb.count(mode, k, per_target=True)
     try:
         # queue kernel (default for equality / Hamming): every first-round depth, tpb
-        for qf in (0, 1, 2, 3, 4, 6, 8):
+        for qf in (0, 1, 2, 3, 4, 5, 6, 7, 8):
             for tpb in (1, 5, 64):
                 sc.set_option("queue_first", qf)
                 sc.set_option("targets_per_block", tpb)

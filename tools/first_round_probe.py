@@ -26,10 +26,12 @@ tb.fill_synthetic(synth.SynthSpec(seed=2, n_clusters=n, row=cols),
                   [(1, int(t)) for t in workload.tiles_for_stype(workload.NOVASEQ_STYPE if NOVA else "hiseq_x")[:tiles]], list(range(50)))
 MODES = ((0, 0, "equality"), (1, 1, "hamming<=1"), (1, 2, "hamming<=2"), (1, 3, "hamming<=3"), (2, 2, "lev<=2"),
          (2, 3, "lev<=3"), (2, 4, "lev<=4"), (2, 5, "lev<=5"), (2, 6, "lev<=6"), (2, 7, "lev<=7"))
+if len(sys.argv) > 1 and sys.argv[1] == "ham":
+    MODES = [m for m in MODES if m[0] == 1]
 if len(sys.argv) > 1 and sys.argv[1] == "lev":
     MODES = [m for m in MODES if m[0] == 2]
 for mode, k, name in MODES:
-    for first in ((0, 1, 2, 3, 4, 6, 8) if mode < 2 else (0,)):
+    for first in ((0, 1, 2, 3, 4, 5, 6, 7, 8) if mode < 2 else (0,)):
         sc.set_option("queue_first", first)
         tb.count(mode, k)
         sc.set_option("profile", 1)

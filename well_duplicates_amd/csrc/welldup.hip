@@ -377,13 +377,15 @@ int launch_queue(wd_ctx *ctx, const ScanArgs &a, dim3 grid)
     // sum_{i<=k} C(r,i) 0.75^i 0.25^(r-i); the first round should leave a few percent alive.
     int first = ctx->queue_first;
     if (first == 0)
-        first = a.k <= 0 ? 2 : (a.k == 1 ? 4 : (a.k <= 3 ? 6 : 8));   // measured on MI355X
+        first = a.k <= 0 ? 2 : (a.k == 1 ? 3 : (a.k == 2 ? 5 : (a.k == 3 ? 6 : 8)));   // measured on MI355X
     switch (first) {
     case 1: hipLaunchKernelGGL((k_scan_q<STRIDED, 1>), grid, dim3(kBlock), lds, ctx->stream, a); break;
     case 2: hipLaunchKernelGGL((k_scan_q<STRIDED, 2>), grid, dim3(kBlock), lds, ctx->stream, a); break;
     case 3: hipLaunchKernelGGL((k_scan_q<STRIDED, 3>), grid, dim3(kBlock), lds, ctx->stream, a); break;
     case 4: hipLaunchKernelGGL((k_scan_q<STRIDED, 4>), grid, dim3(kBlock), lds, ctx->stream, a); break;
+    case 5: hipLaunchKernelGGL((k_scan_q<STRIDED, 5>), grid, dim3(kBlock), lds, ctx->stream, a); break;
     case 6: hipLaunchKernelGGL((k_scan_q<STRIDED, 6>), grid, dim3(kBlock), lds, ctx->stream, a); break;
+    case 7: hipLaunchKernelGGL((k_scan_q<STRIDED, 7>), grid, dim3(kBlock), lds, ctx->stream, a); break;
     default: hipLaunchKernelGGL((k_scan_q<STRIDED, 8>), grid, dim3(kBlock), lds, ctx->stream, a); break;
     }
     return 0;
@@ -974,8 +976,8 @@ int wd_set_option(wd_ctx *ctx, const char *name, int64_t value)
     } else if (n == "queue_kernel") {
         ctx->queue_kernel = value ? 1 : 0;
     } else if (n == "queue_first") {
-        if (value != 0 && value != 1 && value != 2 && value != 3 && value != 4 && value != 6 && value != 8)
-            return fail(ctx, WD_ERR_ARG, "queue_first must be 0 (auto), 1, 2, 3, 4, 6 or 8");
+        if (value < 0 || value > 8)
+            return fail(ctx, WD_ERR_ARG, "queue_first must be 0 (auto) or 1..8");
         ctx->queue_first = (int)value;
     } else {
         return fail(ctx, WD_ERR_ARG, "unknown option " + n);
