@@ -305,7 +305,7 @@ def e2e_probe(device, n_tiles, rows, cols, centre, lvl_off, nbr, cycles=50, thre
     from well_duplicates_amd import count_well_duplicates as cwd
     from well_duplicates_amd.scanner import Scanner, TileBatch
     n = rows * cols
-    threads = threads or min(32, os.cpu_count() or 1)
+    threads = threads or cwd.default_threads()
     spec = synth.SynthSpec(seed=2, n_clusters=n, row=cols, qual_levels=7)
     tiles = [str(t) for t in workload.tiles_for_stype("hiseq_x")[:n_tiles]]
     root = tempfile.mkdtemp(prefix="wd_e2e_")
@@ -341,7 +341,7 @@ def e2e_probe(device, n_tiles, rows, cols, centre, lvl_off, nbr, cycles=50, thre
         levels = lvl_off.shape[1] - 1
         argv = ["-f", tfile, "-n", str(centre.shape[0]), "-l", str(levels), "-s", "hiseq_x", "-r", root, "-i", "1",
                 "-t", ",".join(tiles), "--cycles", "0-%d" % cycles, "-q", "-S", "--threads", str(threads),
-                "--device", str(device), "--tile-batch", str(max(1, n_tiles // 2))]
+                "--device", str(device)]                      # --tile-batch: the CLI's default
 
         def run(extra):
             buf = io.StringIO()
@@ -390,8 +390,9 @@ def e2e_probe(device, n_tiles, rows, cols, centre, lvl_off, nbr, cycles=50, thre
                               "the time to read and copy the compressed bytes"}
             tb.free()
         return {"what": "count_well_duplicates CLI (-e 2 Levenshtein, %d targets x %d levels, -q -S) on %d full-size "
-                        "tiles x %d cycles of .bcl.gz files (gzip -6, 7 quality bins), warm page cache; two batches "
-                        "of %d tiles" % (centre.shape[0], levels, n_tiles, cycles, max(1, n_tiles // 2)),
+                        "tiles x %d cycles of .bcl.gz files (gzip -6, 7 quality bins), warm page cache; the CLI's "
+                        "default settings (batches of about 512 files, %d reader threads)"
+                        % (centre.shape[0], levels, n_tiles, cycles, threads),
                 "tiles": n_tiles, "files": n_tiles * cycles, "gz_bytes": gz_bytes[0], "plane_bytes": plane_bytes,
                 "threads": threads, "seconds": round(best, 4), "s_per_tile": round(best / n_tiles, 4),
                 "plane_gb_per_s": round(plane_bytes / best / 1e9, 3),

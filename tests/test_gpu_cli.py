@@ -85,6 +85,23 @@ def test_cli_tile_batching_and_errors(tmp_path_factory):
                   "-t", "1103", "-i", "1", "-q", "--cycles", "0-50", "-l", "5"])
 
 
+def test_cli_pipeline_of_batches(tmp_path):
+    """Seven tiles in batches of 1, 2 and 3 (the last one short): three batches are on their way at
+    any time and a finished batch's buffers are taken over by the next - report and duplicate log
+    equal the one-batch, one-at-a-time, host-inflated run (whose path the goldens above pin)."""
+    fx = load_fixture("mid")
+    spec = synth.spec_from_dict(fx["spec"])
+    run = fx["runs"][2]                                    # the reference's default metric, with the duplicate log
+    tiles = [str(1101 + i) for i in range(7)]
+    synth.write_run_dir(spec, str(tmp_path), [1], tiles, sorted(run_cycles(run)))
+    fx7 = dict(fx, tiles=tiles, lanes=[1])
+    base = _cli(fx7, str(tmp_path), run, ["--tile-batch", "7", "--serial-ingest", "--host-inflate"])
+    assert base[1].count("Reading tile") == 7 and "edit distance:" in base[1]
+    for extra in (["--tile-batch", "1"], ["--tile-batch", "2"], ["--tile-batch", "3"], [],
+                  ["--tile-batch", "2", "--serial-ingest"], ["--tile-batch", "2", "--host-inflate"]):
+        assert _cli(fx7, str(tmp_path), run, extra) == base, extra
+
+
 def _torchrun(argv, nproc):
     import socket
     import subprocess

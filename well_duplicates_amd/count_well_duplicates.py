@@ -89,10 +89,11 @@ def parse_args(argv=None):
                    help="the one collective under torchrun: nccl = RCCL through torch.distributed; "
                         "wd = RCCL through libwelldup's own binding (wd_allreduce_counts; torch only carries "
                         "the unique id); gloo = CPU, for rehearsals")
-    p.add_argument("--tile-batch", type=int, default=32,
-                   help="tiles kept resident in HBM and scanned per launch")
-    p.add_argument("--threads", type=int, default=min(32, os.cpu_count() or 1),
-                   help="reader threads (gunzip)")
+    p.add_argument("--tile-batch", type=int, default=0,
+                   help="tiles loaded, kept resident in HBM and scanned together (default 0: as many as make "
+                        "about 512 files, what one launch of the GPU decoder holds at once)")
+    p.add_argument("--threads", type=int, default=default_threads(),
+                   help="reader threads (gunzip with --host-inflate)")
     p.add_argument("-o", "--output", default=None,
                    help="write the report to this file instead of stdout")
     p.add_argument("--all-wells", action="store_true",
@@ -126,6 +127,11 @@ def parse_args(argv=None):
 _T0 = [0.0]
 
 
+def default_threads() -> int:
+    """Reader threads (they read files into pinned memory; with --host-inflate they also gunzip)."""
+    return max(1, min(32, os.cpu_count() or 1))
+
+
 def _lap(what: str):
     """WD_CLI_TIMING=1: where the wall clock of a run goes (stderr)."""
     if os.environ.get("WD_CLI_TIMING"):
@@ -156,18 +162,25 @@ def scan_lane(sc: Scanner, reader, lane, tiles, cycle_list, mode, k, csr, wells,
               threads, want_log, overlap=True, interleave=1, gpu_inflate=True):
     """The given tiles of one lane -> ({tile: TileCounts}, {tile: [log lines]}).
 
-    Double-buffered: while the GPU scans batch n (and its report rows and log lines are put
-    together), the loader threads are already gunzipping and copying batch n + 1 into a second
-    TileBatch (the ctypes calls release the GIL).  Whatever goes wrong, every loader thread has
+    Pipelined: while the GPU scans batch n (and its report rows and log lines are put together),
+    batch n + 1 is being inflated and batch n + 2 read and copied, each into a TileBatch of its own
+    (the ctypes calls release the GIL).  Whatever goes wrong, every loader thread has
     finished before a TileBatch is freed or the exception leaves this function: the threads
     write through the scanner's copy streams into the batches' planes.
     """
     centre, lvl_off, nbr = csr
     levels = lvl_off.shape[1] - 1
     counts, logs = {}, {}
+    if tile_batch <= 0:
+        # about 512 files per batch - what one launch of the GPU decoder holds at once - in batches of
+        # equal size (a short last batch would cost a full round of the decoder)
+        per = max(1, 512 // max(1, len(cycle_list)))
+        n_batches = max(1, -(-len(tiles) // per))
+        tile_batch = max(1, -(-len(tiles) // n_batches))
     batches = [tiles[b0:b0 + tile_batch] for b0 in range(0, len(tiles), tile_batch)]
     pool = ThreadPoolExecutor(max_workers=max(1, threads))
     live = []                               # TileBatches not yet freed
+    spare = []                              # finished ones whose buffers the next batch takes over
 
     def start(chunk):
         """Submit every load of a batch; returns at once."""
@@ -180,7 +193,10 @@ def scan_lane(sc: Scanner, reader, lane, tiles, cycle_list, mode, k, csr, wells,
         if wells.size and (wells[-1] >= n_clusters or wells[0] < 0):
             raise IndexError("Requested cluster %i is out of range.  Highest on this "
                              "tile is %i." % (int(wells[-1]), n_clusters - 1))
-        tb = TileBatch(sc, len(chunk), len(cycle_list), n_clusters, interleave=interleave)
+        # (a finished batch's buffers are taken over: freeing device memory would wait for the
+        # decoder's kernels of the batches behind)
+        tb = TileBatch(sc, len(chunk), len(cycle_list), n_clusters, interleave=interleave,
+                       reuse=spare.pop() if spare else None)
         live.append(tb)
         # ingest: every (tile, cycle) file is gunzipped into pinned memory and copied to the GPU
         # by libwelldup (wd_load_bcl_gz).  Runs without .bcl.gz files are NovaSeq runs: the
@@ -231,16 +247,21 @@ def scan_lane(sc: Scanner, reader, lane, tiles, cycle_list, mode, k, csr, wells,
             planes = [pool.submit(load, i, c) for i, c in jobs]
         return _Loading(chunk, handles, tb, filt + planes)
 
-    def release(tb):
+    def release(tb, keep=False):
         live.remove(tb)
-        tb.free()
+        if keep:
+            spare.append(tb)
+        else:
+            tb.free()
 
     try:
-        # two batches on their way at any time: the second one's files are read and copied while the
-        # first one's are still being inflated (the GPU decoder's time per batch does not shrink
-        # with the batch), and both while the one before is scanned and reported
+        # three batches on their way at any time: one's files are read and copied while the one before
+        # is still being inflated (the GPU decoder's time per batch does not shrink with the batch)
+        # and the one before that is scanned and reported - the library serves the batch calls in
+        # the order they were made
+        depth = 3 if overlap else 1
         ahead = []
-        for b in batches[:2 if overlap else 1]:
+        for b in batches[:depth]:
             ahead.append(start(b))
         for bi in range(len(batches)):
             cur = ahead.pop(0)
@@ -263,9 +284,9 @@ def scan_lane(sc: Scanner, reader, lane, tiles, cycle_list, mode, k, csr, wells,
                 sc.hitlog_enable(0)
                 order = np.lexsort((hits["slot"], hits["target"], hits["tile"]))
                 hits = hits[order]
-            release(tb)
-            if overlap and bi + 2 < len(batches):
-                ahead.append(start(batches[bi + 2]))
+            release(tb, keep=bi + depth < len(batches))
+            if overlap and bi + depth < len(batches):
+                ahead.append(start(batches[bi + depth]))
             for i, t in enumerate(chunk):
                 counts[t] = report.TileCounts.from_block(blocks[i], levels)
                 if want_log:
@@ -289,6 +310,8 @@ def scan_lane(sc: Scanner, reader, lane, tiles, cycle_list, mode, k, csr, wells,
         pool.shutdown(wait=True, cancel_futures=True)
         for tb in list(live):
             release(tb)
+        for tb in spare:
+            tb.free()
     return counts, logs
 
 
@@ -375,7 +398,7 @@ def main(argv=None):
                     if not lane_tiles:
                         continue
                     counts, lane_logs = scan_lane(sc, reader, lane, lane_tiles, cycle_list, mode, k, csr, wells,
-                                                  max(1, args.tile_batch), args.threads,
+                                                  max(0, args.tile_batch), args.threads,
                                                   0 if (args.quiet or args.all_wells) else len(cycles),
                                                   overlap=not args.serial_ingest,
                                                   interleave=4 if args.layout == "interleaved" else 1,

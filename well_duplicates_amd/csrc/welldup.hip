@@ -256,7 +256,7 @@ struct wd_ctx {
     int inflate_waves = 0;                             // option: waves per file (1, 4, 8; 0 = by the launch's size)
     hipStream_t inflate_streams[kInflateStreams + 1] = {};
     hipEvent_t inflate_ready[kInflateStreams] = {};    // a launch's files are all in the arena
-    // what a batch keeps until its last kernel is done; two, so that the next batch's files are read
+    // what a batch keeps until its last kernel is done; several, so that the next batch's files are read
     // and copied while this batch's are still being decoded
     struct InflateSlot {
         std::mutex mu;
@@ -267,9 +267,13 @@ struct wd_ctx {
         size_t jobs_cap = 0;
         hipEvent_t done = nullptr;                     // the batch's results are on the host
     };
-    InflateSlot inflate_slots[2];
+    static constexpr int kInflateSlots = 3;            // one batch read, one decoded, one waiting for its results
+    InflateSlot inflate_slots[kInflateSlots];
+    // One batch at a time reads, copies and launches, in the order the calls came in (a ticket each).
     std::atomic<unsigned> inflate_calls{0};
-    std::mutex inflate_mu;                             // one batch at a time reads, copies and launches
+    unsigned inflate_serving = 0;                      // under inflate_mu
+    std::mutex inflate_mu;
+    std::condition_variable inflate_cv;
     std::atomic<long long> inflate_files_gpu{0}, inflate_files_host{0};   // how the files of all batches were decoded
     std::atomic<long long> inflate_us_per_file{0};     // last batch: a file's time in the decode kernel, mean, microseconds
 };
@@ -1964,10 +1968,39 @@ int wd_load_bcl_gz_strided(wd_ctx *ctx, const char *path, uint8_t *dst_dev, int6
 // ---- a batch of .bcl.gz files through the GPU decoder ------------------------------------------
 namespace {
 
+// A batch call's turn at the shared ring, the copy stream and the launches: calls are served in the
+// order they arrived (so that batches a caller queued up are read in that order), one at a time.
+// The slot is chosen and locked while the turn is held: a slot's previous holder has had its turn
+// and only waits for the GPU, and no later call can take the slot first.
+struct InflateTurn {
+    wd_ctx *ctx;
+    unsigned ticket;
+    bool held = true;
+    explicit InflateTurn(wd_ctx *c) : ctx(c), ticket(c->inflate_calls.fetch_add(1))
+    {
+        std::unique_lock<std::mutex> lk(ctx->inflate_mu);
+        ctx->inflate_cv.wait(lk, [&] { return ctx->inflate_serving == ticket; });
+    }
+    void unlock()
+    {
+        if (!held)
+            return;
+        held = false;
+        {
+            std::lock_guard<std::mutex> lk(ctx->inflate_mu);
+            ctx->inflate_serving = ticket + 1;
+        }
+        ctx->inflate_cv.notify_all();
+    }
+    ~InflateTurn() { unlock(); }
+    InflateTurn(const InflateTurn &) = delete;
+    InflateTurn &operator=(const InflateTurn &) = delete;
+};
+
 // buffers of a batch: pinned ring, streams, arena for `arena_bytes` of compressed files, n job slots
 int inflate_prepare(wd_ctx *ctx, wd_ctx::InflateSlot &sl, int n_chunks, size_t arena_bytes, size_t n_jobs)
 {
-    if (!sl.done && hipEventCreateWithFlags(&sl.done, hipEventDisableTiming) != hipSuccess)
+    if (!sl.done && hipEventCreateWithFlags(&sl.done, hipEventDisableTiming | hipEventBlockingSync) != hipSuccess)
         return WD_ERR_HIP;
     if (ctx->inflate_chunk_cap != ctx->inflate_chunk_bytes) {            // the option changed: new buffers
         // (the batch before may still be copying out of the old ones)
@@ -1982,7 +2015,7 @@ int inflate_prepare(wd_ctx *ctx, wd_ctx::InflateSlot &sl, int n_chunks, size_t a
     }
     for (int c = 0; c < n_chunks; c++) {
         wd_ctx::InflateChunk &ch = ctx->inflate_chunks[c];
-        if (!ch.copied && hipEventCreateWithFlags(&ch.copied, hipEventDisableTiming) != hipSuccess)
+        if (!ch.copied && hipEventCreateWithFlags(&ch.copied, hipEventDisableTiming | hipEventBlockingSync) != hipSuccess)
             return WD_ERR_HIP;
         if (!ch.pinned && hipHostMalloc((void **)&ch.pinned, ctx->inflate_chunk_cap + 64, hipHostMallocDefault) != hipSuccess)
             return WD_ERR_NOMEM;
@@ -2039,9 +2072,9 @@ int wd_load_tile_files_batch(wd_ctx *ctx, int n_files, const char *const *paths,
     if (hipSetDevice(ctx->device) != hipSuccess)
         return WD_ERR_HIP;
     // a slot for the whole call, the shared ring / streams only while this batch is read and launched
-    wd_ctx::InflateSlot &slot = ctx->inflate_slots[ctx->inflate_calls.fetch_add(1) & 1];
+    InflateTurn batch_lock(ctx);
+    wd_ctx::InflateSlot &slot = ctx->inflate_slots[batch_lock.ticket % wd_ctx::kInflateSlots];
     std::lock_guard<std::mutex> slot_lock(slot.mu);
-    std::unique_lock<std::mutex> batch_lock(ctx->inflate_mu);
     threads = std::max(1, std::min(threads, 256));
     constexpr int kChunks = wd_ctx::kInflateChunks, kStreams = wd_ctx::kInflateStreams;
     const size_t chunk_bytes = ctx->inflate_chunk_bytes;
@@ -2498,9 +2531,9 @@ int wd_load_cbcl_batch(wd_ctx *ctx, int n, const char *const *paths, const int *
         return WD_ERR_ARG;
     if (hipSetDevice(ctx->device) != hipSuccess)
         return WD_ERR_HIP;
-    wd_ctx::InflateSlot &slot = ctx->inflate_slots[ctx->inflate_calls.fetch_add(1) & 1];
+    InflateTurn batch_lock(ctx);
+    wd_ctx::InflateSlot &slot = ctx->inflate_slots[batch_lock.ticket % wd_ctx::kInflateSlots];
     std::lock_guard<std::mutex> slot_lock(slot.mu);
-    std::unique_lock<std::mutex> batch_lock(ctx->inflate_mu);
     threads = std::max(1, std::min(threads, 256));
     constexpr int kChunks = wd_ctx::kInflateChunks, kStreams = wd_ctx::kInflateStreams;
     const size_t chunk_bytes = ctx->inflate_chunk_bytes;

@@ -385,7 +385,10 @@ class TileBatch:
     (device generator) or `upload_tile` (host bytes).
     """
 
-    def __init__(self, scanner: Scanner, n_tiles: int, L: int, n_clusters: int, interleave: int = 1):
+    def __init__(self, scanner: Scanner, n_tiles: int, L: int, n_clusters: int, interleave: int = 1,
+                 reuse: Optional["TileBatch"] = None):
+        """reuse: a batch that is done with - its buffers are taken over when they are large enough
+        (freeing device memory waits for every kernel in flight), else freed."""
         assert interleave in (1, 4)
         self.sc = scanner
         self.n_tiles, self.L, self.N = n_tiles, L, n_clusters
@@ -395,9 +398,18 @@ class TileBatch:
         self.slot_bytes = self.n_pad * interleave
         self.plane_bytes = n_tiles * self.groups * self.slot_bytes
         self.filter_bytes = n_tiles * self.n_pad
-        self.d_planes = scanner.malloc(max(1, self.plane_bytes))
-        self.d_filters = scanner.malloc(max(1, self.filter_bytes))
-        self.d_tmp = scanner.malloc(4 * self.n_pad) if interleave == 4 else 0
+        tmp_bytes = 4 * self.n_pad if interleave == 4 else 0
+        if (reuse is not None and reuse.sc is scanner and reuse.d_planes and reuse._cap[0] >= self.plane_bytes
+                and reuse._cap[1] >= self.filter_bytes and reuse._cap[2] >= tmp_bytes):
+            self.d_planes, self.d_filters, self.d_tmp, self._cap = reuse.d_planes, reuse.d_filters, reuse.d_tmp, reuse._cap
+            reuse.d_planes = reuse.d_filters = reuse.d_tmp = 0
+        else:
+            if reuse is not None:
+                reuse.free()
+            self.d_planes = scanner.malloc(max(1, self.plane_bytes))
+            self.d_filters = scanner.malloc(max(1, self.filter_bytes))
+            self.d_tmp = scanner.malloc(tmp_bytes) if tmp_bytes else 0
+            self._cap = (self.plane_bytes, self.filter_bytes, tmp_bytes)
         self.tables = Scanner._tables(self.plane_ptrs(), self.filter_ptrs(), L)
 
     def plane_ptr(self, tile: int, cycle: int) -> int:
@@ -463,7 +475,7 @@ class TileBatch:
             self.sc.set_option("well_stride", 1)
 
     def free(self):
-        self.sc.free(self.d_planes)
-        self.sc.free(self.d_filters)
-        if self.d_tmp:
-            self.sc.free(self.d_tmp)
+        for ptr in (self.d_planes, self.d_filters, self.d_tmp):
+            if ptr:
+                self.sc.free(ptr)
+        self.d_planes = self.d_filters = self.d_tmp = 0
