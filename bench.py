@@ -495,6 +495,9 @@ def main():
     jobs = [torch.zeros((chunk, world * args.tiles, ncnt), dtype=torch.int64, device="cuda") for _ in range(2)]
     pending = [None, None]
     turn = [0]
+    # this rank's rows of step 0 of either block, and the bytes from one step's slab to the next
+    slab_bytes = world * args.tiles * ncnt * 8
+    row_ptr = [j.data_ptr() + rank * args.tiles * ncnt * 8 for j in jobs]
 
     def merge(buf, used):
         view = jobs[buf][:used]
@@ -524,9 +527,8 @@ def main():
             n = min(chunk, n_steps - done)
             if use_dist:
                 jobs[buf][:n].zero_()           # the other ranks' rows (a scan clears its own)
-            for s_i in range(n):
-                rows = jobs[buf][s_i, rank * args.tiles:(rank + 1) * args.tiles]
-                sc.scan_async(tb.tables, args.tiles, L, n_clusters, mode, k, rows.data_ptr())
+            for s_i in range(n):                # (addresses worked out ahead: the loop only launches)
+                sc.scan_async(tb.tables, args.tiles, L, n_clusters, mode, k, row_ptr[buf] + s_i * slab_bytes)
             if use_dist:
                 merge(buf, n)
             done += n
