@@ -81,6 +81,31 @@ def _load_and_check(sc, tmp_path, files, n, threads=4):
     return by_gpu, by_host
 
 
+def test_small_window_form(sc, tmp_path):
+    """A launch whose files all expand less than 1.75-fold is decoded by the four-wave kernel with the
+    small window buffers (three files per CU): planes that compress like binned qualities, noise, and
+    files with stretches that expand far more than the window holds (cut windows, or the host)."""
+    sc.set_option("inflate_waves", 4)
+    n = 400003
+    pl = _planes(n, ["q39", "noise", "runs"])
+    rng = np.random.default_rng(11)
+    files = {"q39_l6": (_bcl(pl["q39"], 6), pl["q39"]), "noise_l6": (_bcl(pl["noise"], 6), pl["noise"])}
+    for k in range(6):
+        mixed = pl["noise"].copy()
+        at = int(rng.integers(0, n - 70000))
+        mixed[at:at + 40000] = pl["runs"][:40000]
+        at = int(rng.integers(0, n - 70000))
+        mixed[at:at + int(rng.integers(100, 30000))] = int(rng.integers(0, 256))
+        files["mixed%d" % k] = (_bcl(mixed, 6 if k % 2 else 9), mixed)
+    for name, (data, payload) in files.items():
+        assert (len(payload) + 4) * 4 <= len(data) * 7, name      # what the loader's choice goes by
+    try:
+        by_gpu, by_host = _load_and_check(sc, tmp_path, files, n)
+    finally:
+        sc.set_option("inflate_waves", 0)
+    assert by_gpu + by_host == len(files) and by_gpu >= 2, (by_gpu, by_host)
+
+
 @pytest.mark.parametrize("waves", [1, 4, 8])
 def test_batch_matches_gzip_module(sc, tmp_path, waves):
     """Every kernel variant (waves per file) on every kind of stream."""
@@ -98,6 +123,12 @@ def test_batch_matches_gzip_module(sc, tmp_path, waves):
     co = zlib.compressobj(6, zlib.DEFLATED, 31)
     parts = [co.compress(raw[i:i + 50000]) + co.flush(zlib.Z_SYNC_FLUSH) for i in range(0, len(raw), 50000)]
     files["flushes"] = (b"".join(parts) + co.flush(), pl["q7"])
+    # little expansion over the whole file (the launch takes the decoder's small-window form when all
+    # its files are like that - see test_small_window_form) but stretches that expand a lot
+    mixed = pl["noise"].copy()
+    mixed[100000:160000] = pl["runs"][:60000]
+    mixed[300000:330000] = 7
+    files["mixed"] = (_bcl(mixed, 6), mixed)
     # a file name in the gzip header (FNAME), as `gzip file` writes it
     files["named"] = (gzip.compress(raw, 6)[:3] + b"\x08" + gzip.compress(raw, 6)[4:10] + b"s_1_1101.bcl\0"
                       + gzip.compress(raw, 6)[10:], pl["q7"])

@@ -15,11 +15,13 @@ from well_duplicates_amd import synth
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.fixture(scope="module", params=[1, 4], ids=["one-wave", "four-waves"])
+@pytest.fixture(scope="module", params=[(1, 512, 2), (4, 256, 2), (4, 256, 4)],
+                ids=["one-wave", "four-waves", "four-waves-small-windows"])
 def emu(request, tmp_path_factory):
-    exe = str(tmp_path_factory.mktemp("emu") / ("inflate_emu_w%d" % request.param))
-    subprocess.check_call(["g++", "-O2", "-std=c++17", "-pthread", "-DEMU_WAVES=%d" % request.param,
-                           os.path.join(REPO, "tools", "inflate_emu.cpp"), "-lz", "-o", exe])
+    waves, span, outdiv = request.param
+    exe = str(tmp_path_factory.mktemp("emu") / ("inflate_emu_w%d_d%d" % (waves, outdiv)))
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-pthread", "-DEMU_WAVES=%d" % waves, "-DEMU_SPAN=%d" % span,
+                           "-DEMU_OUTDIV=%d" % outdiv, os.path.join(REPO, "tools", "inflate_emu.cpp"), "-lz", "-o", exe])
     return exe
 
 

@@ -4,7 +4,7 @@
 // match resolution, every error exit - be run under a sanitizer and compared with zlib before a
 // kernel is launched on a shared GPU.
 //
-//   g++ -O1 -g -std=c++17 -fsanitize=address,undefined -pthread [-DEMU_WAVES=1|4] [-DEMU_SPAN=512|256]
+//   g++ -O1 -g -std=c++17 -fsanitize=address,undefined -pthread [-DEMU_WAVES=1|4] [-DEMU_SPAN=512|256] [-DEMU_OUTDIV=2|4]
 //       tools/inflate_emu.cpp -lz -o inflate_emu
 //   ./inflate_emu file.gz [...]           decode, compare with zlib, print the statistics
 //   ./inflate_emu --fuzz SEED COUNT file.gz   corrupt the file COUNT times; the decoder must end with
@@ -90,7 +90,10 @@ struct Job {
 #ifndef EMU_SPAN
 #define EMU_SPAN 512
 #endif
-static InfLdsT<EMU_WAVES, EMU_SPAN> g_lds;
+#ifndef EMU_OUTDIV
+#define EMU_OUTDIV 2
+#endif
+static InfLdsT<EMU_WAVES, EMU_SPAN, EMU_OUTDIV> g_lds;
 static Job g_job;
 
 static void *lane_main(void *arg)

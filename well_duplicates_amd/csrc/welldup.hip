@@ -39,6 +39,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <condition_variable>
 #include <memory>
 #include <mutex>
@@ -2193,11 +2194,15 @@ int wd_load_tile_files_batch(wd_ctx *ctx, int n_files, const char *const *paths,
     const int si = (int)(batch_lock.ticket % kStreams);                  // consecutive batches decode on alternate streams
     int launch = 0;
     size_t j0 = 0;                                                       // first job of the launch being gathered
+    double wait_read_s = 0, wait_copy_s = 0;                             // (WD_INFLATE_STATS) what the chunk loop waits for
+    const auto loop_t0 = std::chrono::steady_clock::now();
     for (int g = 0; g < n_groups && hip_rc == WD_OK; g++) {
         Group &grp = *groups[(size_t)g];
         {
+            const auto w0 = std::chrono::steady_clock::now();
             std::unique_lock<std::mutex> lk(mu);
             cv.wait(lk, [&] { return grp.remaining.load() == 0; });
+            wait_read_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - w0).count();
         }
         wd_ctx::InflateChunk &ch = ctx->inflate_chunks[g % kChunks];
         uint8_t *dev = slot.arena + grp.arena_at;
@@ -2250,8 +2255,16 @@ int wd_load_tile_files_batch(wd_ctx *ctx, int n_files, const char *const *paths,
                 // waves per file: eight while every file of the launch gets a CU of its own (26 ms per
             // file), else four (39 ms, two files per CU); one wave per file (89 ms, three per CU) on request
             const int waves = ctx->inflate_waves ? ctx->inflate_waves : nj <= 256 ? 8 : 4;
+            // (four waves: three files per CU instead of two when no file of the launch expands much)
+            bool slim = true;
+            for (size_t q = j0; q < job_file.size() && slim; q++) {
+                const int i = job_file[q];
+                slim = (trailer[(size_t)i] >> 32) * 4 <= (uint64_t)size[(size_t)i] * 7;
+            }
             if (waves == 8)
                 hipLaunchKernelGGL((k_inflate<8, 256>), dim3(nj), dim3(512), 0, stream, slot.d_jobs + j0, slot.d_res + j0);
+            else if (waves == 4 && slim)
+                hipLaunchKernelGGL((k_inflate<4, 256, 4>), dim3(nj), dim3(256), 0, stream, slot.d_jobs + j0, slot.d_res + j0);
             else if (waves == 4)
                 hipLaunchKernelGGL((k_inflate<4, 256>), dim3(nj), dim3(256), 0, stream, slot.d_jobs + j0, slot.d_res + j0);
             else
@@ -2272,13 +2285,17 @@ int wd_load_tile_files_batch(wd_ctx *ctx, int n_files, const char *const *paths,
             j0 = job_file.size();
             launch++;
         }
-        if (g + 1 >= kChunks) {                                          // the chunk group g + 1 wants: is its copy done?
-            if (hipEventSynchronize(ctx->inflate_chunks[(g + 1) % kChunks].copied) != hipSuccess) {
+        if (g >= 1) {
+            // group g - 1 + kChunks wants the chunk of group g - 1: once that copy (asked for a turn
+            // ago) is done, the readers may fill every chunk but the one just sent off
+            const auto w0 = std::chrono::steady_clock::now();
+            if (hipEventSynchronize(ctx->inflate_chunks[(g - 1) % kChunks].copied) != hipSuccess) {
                 hip_rc = WD_ERR_HIP;
                 break;
             }
+            wait_copy_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - w0).count();
             std::lock_guard<std::mutex> lk(mu);
-            free_upto = g + 2;
+            free_upto = g + kChunks;
             cv.notify_all();
         }
     }
@@ -2289,6 +2306,10 @@ int wd_load_tile_files_batch(wd_ctx *ctx, int n_files, const char *const *paths,
     }
     for (auto &t : pool)
         t.join();
+    if (getenv("WD_INFLATE_STATS"))
+        fprintf(stderr, "[wd inflate] chunk loop %.1f ms for %d chunks: waited %.1f ms for the readers, %.1f ms for chunk copies\n",
+                1e3 * std::chrono::duration<double>(std::chrono::steady_clock::now() - loop_t0).count(), n_groups,
+                1e3 * wait_read_s, 1e3 * wait_copy_s);
     // the next batch may start reading; this one waits for its last results
     // (.filter copies ride on the copy stream: the decode stream's event must come after them)
     if (hip_rc == WD_OK && n_groups &&
@@ -2326,12 +2347,13 @@ int wd_load_tile_files_batch(wd_ctx *ctx, int n_files, const char *const *paths,
     if (!job_file.empty())
         ctx->inflate_us_per_file = (long long)(real_sum / 100 / job_file.size());     // t_real counts 10 ns
     if (want_stats && !job_file.empty()) {
-        int occ[3] = {-1, -1, -1};
+        int occ[4] = {-1, -1, -1, -1};
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ[3], (const void *)k_inflate<4, 256, 4>, 256, 0);
         (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ[0], (const void *)k_inflate<1, 512>, 64, 0);
         (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ[1], (const void *)k_inflate<4, 256>, 256, 0);
         (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ[2], (const void *)k_inflate<8, 256>, 512, 0);
-        fprintf(stderr, "[wd inflate] workgroups per CU by the runtime's count: 1 wave %d, 4 waves %d, 8 waves %d\n", occ[0],
-                occ[1], occ[2]);
+        fprintf(stderr, "[wd inflate] workgroups per CU by the runtime's count: 1 wave %d, 4 waves %d (slim: %d), 8 waves %d\n", occ[0],
+                occ[1], occ[3], occ[2]);
         const double nf = (double)job_file.size();
         fprintf(stderr, "[wd inflate] files %d in %d chunks | Mclk per file: header %.2f tables %.2f stage %.2f passes %.2f "
                         "emit %.2f resolve %.2f (first sweep %.2f) flush %.2f total %.2f = %.1f ms at %.2f GHz | per file: windows %.0f passes %.0f "
@@ -2736,13 +2758,13 @@ int wd_load_cbcl_batch(wd_ctx *ctx, int n, const char *const *paths, const int *
             hip_rc = WD_ERR_HIP;
             break;
         }
-        if (g + 1 >= kChunks) {
-            if (hipEventSynchronize(ctx->inflate_chunks[(g + 1) % kChunks].copied) != hipSuccess) {
+        if (g >= 1) {                                            // (as in wd_load_tile_files_batch)
+            if (hipEventSynchronize(ctx->inflate_chunks[(g - 1) % kChunks].copied) != hipSuccess) {
                 hip_rc = WD_ERR_HIP;
                 break;
             }
             std::lock_guard<std::mutex> lk(mu);
-            free_upto = g + 2;
+            free_upto = g + kChunks;
             cv.notify_all();
         }
     }
