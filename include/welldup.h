@@ -207,14 +207,18 @@ int wd_load_filter(wd_ctx *ctx, const char *path, uint8_t *dst_dev, int64_t n_cl
 /* A batch of .bcl.gz files (typically all cycles of a few tiles) decoded ON THE GPU: the same
  * contract as n_files calls of wd_load_bcl_gz (bcl_direct_reader.py:200-216, :333-345), file i ->
  * dst_dev[i] (4-byte aligned, n_clusters bytes).  `threads` host threads only read the compressed
- * files into pinned memory; the compressed bytes cross PCIe, one wave per file inflates them
- * (csrc/gpu_inflate.inc: the 64 lanes decode 64 pieces of a block's bit stream at once), a second
+ * files into pinned memory; the compressed bytes cross PCIe, four or eight waves per file inflate them
+ * (csrc/gpu_inflate.inc: every lane decodes a piece of a block's bit stream), a second
  * kernel takes the CRC-32 and the gzip trailer (CRC, length), the cluster count and the plane size
  * are checked.  The GPU decoder is an accelerator, not an authority: a file it declines or whose
  * checks fail (corrupt, truncated, several members, header options, a piece of the stream that
  * expands more than 256-fold) is loaded again by wd_load_bcl_gz, whose return code is the one
  * reported.  rc (nullable): n_files WD_* codes; the return value is the first non-zero one.
- * One batch at a time per context (calls are serialised); safe beside the other loaders.
+ * THREAD-SAFE, and meant to be called from several threads: the calls take turns at the pinned ring
+ * and the copy stream in the order they were made, and up to three are in flight - one reading its
+ * files, one being decoded, one waiting for its results - so a caller that keeps three batches of
+ * about 512 files queued (what one launch of the decoder holds) sees the rate of the chunk copies.
+ * Safe beside the other loaders.
  * wd_get_option "inflate_files_gpu" / "inflate_files_host" count how the files of all batches were
  * decoded; option "inflate_chunk_mb" (default 16) sizes the 4 pinned staging chunks, "inflate_waves"
  * (0 = by the launch's size, 1, 4, 8) how many waves decode one file together. */
