@@ -2,7 +2,8 @@
 """Soak of the GPU DEFLATE decoder: thousands of damaged .bcl.gz files (bit flips, truncations,
 noise runs, header damage; several kinds of payload and compression level), a batch per launch.  Every
 file must come back with the verdict Python's gzip module gives the same bytes: the same plane, or an
-error - and the process must come back at all."""
+error - and the process must come back at all.
+Usage: inflate_soak.py [rounds] [files per round] [seed] [slim]"""
 import gzip
 import os
 import sys
@@ -29,6 +30,11 @@ co = zlib.compressobj(6, zlib.DEFLATED, 31, 8, zlib.Z_FIXED)
 bases.append(co.compress(synth.bcl_file_bytes(runs)) + co.flush())
 stride = (n + 255) // 256 * 256
 sc = Scanner(0)
+if len(sys.argv) > 4 and sys.argv[4] == "slim":
+    # only payloads that expand little, four waves per file: the launches take the decoder's
+    # small-window form (k_inflate<4, 256, 4>) whenever the damage leaves the trailers' lengths small
+    bases = bases[:3]
+    sc.set_option("inflate_waves", 4)
 buf = sc.malloc(stride * per_round + 256)
 tmp = tempfile.mkdtemp(prefix="wd_soak_")
 agree = ok_planes = 0
