@@ -2192,7 +2192,6 @@ int wd_load_tile_files_batch(wd_ctx *ctx, int n_files, const char *const *paths,
     int hip_rc = WD_OK;
     hipStream_t copy_stream = ctx->inflate_streams[kStreams];
     const int si = (int)(batch_lock.ticket % kStreams);                  // consecutive batches decode on alternate streams
-    int launch = 0;
     size_t j0 = 0;                                                       // first job of the launch being gathered
     double wait_read_s = 0, wait_copy_s = 0;                             // (WD_INFLATE_STATS) what the chunk loop waits for
     const auto loop_t0 = std::chrono::steady_clock::now();
@@ -2252,29 +2251,32 @@ int wd_load_tile_files_batch(wd_ctx *ctx, int n_files, const char *const *paths,
                     hip_rc = WD_ERR_HIP;
                     break;
                 }
-                // waves per file: eight while every file of the launch gets a CU of its own (26 ms per
-            // file), else four (39 ms, two files per CU); one wave per file (89 ms, three per CU) on request
-            const int waves = ctx->inflate_waves ? ctx->inflate_waves : nj <= 256 ? 8 : 4;
-            // (four waves: three files per CU instead of two when no file of the launch expands much)
-            bool slim = true;
-            for (size_t q = j0; q < job_file.size() && slim; q++) {
-                const int i = job_file[q];
-                slim = (trailer[(size_t)i] >> 32) * 4 <= (uint64_t)size[(size_t)i] * 7;
-            }
-            if (waves == 8)
-                hipLaunchKernelGGL((k_inflate<8, 256>), dim3(nj), dim3(512), 0, stream, slot.d_jobs + j0, slot.d_res + j0);
-            else if (waves == 4 && slim)
-                hipLaunchKernelGGL((k_inflate<4, 256, 4>), dim3(nj), dim3(256), 0, stream, slot.d_jobs + j0, slot.d_res + j0);
-            else if (waves == 4)
-                hipLaunchKernelGGL((k_inflate<4, 256>), dim3(nj), dim3(256), 0, stream, slot.d_jobs + j0, slot.d_res + j0);
-            else
-                hipLaunchKernelGGL((k_inflate<1, 512>), dim3(nj), dim3(64), 0, stream, slot.d_jobs + j0, slot.d_res + j0);
-            hipLaunchKernelGGL(k_inflate_crc, dim3(nj), dim3(256), 0, stream, slot.d_jobs + j0, slot.d_res + j0);
-            if (well_stride == 4 && n_clusters > 0)
-                for (unsigned q = 0; q < nj; q++)
-                    hipLaunchKernelGGL(k_scatter_plane4, dim3((unsigned)((n_clusters + 4ll * kBlock - 1) / (4ll * kBlock))),
-                                       dim3(kBlock), 0, stream, slot.h_jobs[j0 + q].obase + 4, (long long)n_clusters,
-                                       dst_dev[job_file[j0 + q]]);
+                // waves per file: eight while every file of the launch gets a CU of its own (24 ms per
+                // file), else four (34 ms, two files per CU - three, 36 ms, when no file of the launch
+                // expands much: the small-window form); one wave per file (89 ms, three per CU) on request
+                const int waves = ctx->inflate_waves ? ctx->inflate_waves : nj <= 256 ? 8 : 4;
+                bool slim = true;
+                for (size_t q = j0; q < job_file.size() && slim; q++) {
+                    const int i = job_file[q];
+                    slim = (trailer[(size_t)i] >> 32) * 4 <= (uint64_t)size[(size_t)i] * 7;
+                }
+                InfJob *dj = slot.d_jobs + j0;
+                InfResult *dr = slot.d_res + j0;
+                if (waves == 8)
+                    hipLaunchKernelGGL((k_inflate<8, 256>), dim3(nj), dim3(512), 0, stream, dj, dr);
+                else if (waves == 4 && slim)
+                    hipLaunchKernelGGL((k_inflate<4, 256, 4>), dim3(nj), dim3(256), 0, stream, dj, dr);
+                else if (waves == 4)
+                    hipLaunchKernelGGL((k_inflate<4, 256>), dim3(nj), dim3(256), 0, stream, dj, dr);
+                else
+                    hipLaunchKernelGGL((k_inflate<1, 512>), dim3(nj), dim3(64), 0, stream, dj, dr);
+                hipLaunchKernelGGL(k_inflate_crc, dim3(nj), dim3(256), 0, stream, dj, dr);
+                if (well_stride == 4 && n_clusters > 0)
+                    for (unsigned q = 0; q < nj; q++)
+                        hipLaunchKernelGGL(k_scatter_plane4,
+                                           dim3((unsigned)((n_clusters + 4ll * kBlock - 1) / (4ll * kBlock))), dim3(kBlock), 0,
+                                           stream, slot.h_jobs[j0 + q].obase + 4, (long long)n_clusters,
+                                           dst_dev[job_file[j0 + q]]);
                 if (hipGetLastError() != hipSuccess ||
                     hipMemcpyAsync(slot.h_res + j0, slot.d_res + j0, sizeof(InfResult) * nj,
                                    hipMemcpyDeviceToHost, stream) != hipSuccess) {
@@ -2283,7 +2285,6 @@ int wd_load_tile_files_batch(wd_ctx *ctx, int n_files, const char *const *paths,
                 }
             }
             j0 = job_file.size();
-            launch++;
         }
         if (g >= 1) {
             // group g - 1 + kChunks wants the chunk of group g - 1: once that copy (asked for a turn
