@@ -50,7 +50,7 @@ sys.path.insert(0, REPO)
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
@@ -86,7 +86,57 @@ def parse():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="collective backend for N > 1: nccl = RCCL over xGMI (default); gloo = "
                          "rehearsal of the multi-rank logic with several ranks on ONE GPU")
-    return ap.parse_args()
+    ap.add_argument("--master-port", type=int, default=0,
+                    help="rendezvous port when bench.py starts its own ranks (0 = a free one)")
+    ap.add_argument("--first-lane", type=int, default=1, help="rank r scans lane FIRST_LANE + r")
+    ap.add_argument("--dump-block", default=None,
+                    help="rank 0 saves the last step's merged [ranks*tiles, 1+5*levels] counter block here (.npy)")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="print the launcher's command line (JSON) instead of running it; touches no GPU")
+    return ap.parse_args(argv)
+
+
+def launcher_argv(gpus, argv, port):
+    """The child command `bench.py --gpus N` starts when it was not started under torchrun: one
+    rank per GPU of this node (the driver's own command line for N > 1, CONTRACT: --nnodes=1
+    --nproc-per-node N --master-addr 127.0.0.1)."""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(gpus),
+            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+
+
+def free_port():
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch_ranks(args, argv):
+    """`python bench.py --gpus N` outside torchrun: start the N ranks as a CHILD process (never an
+    exec, and before this process has made any GPU / torch.cuda call - it never makes one), relay
+    the child's output, leave with its exit code."""
+    import subprocess
+    cmd = launcher_argv(args.gpus, [a for a in argv if a != "--dry-run"], args.master_port or free_port())
+    if args.dry_run:
+        print(json.dumps({"launcher": cmd}))
+        return 0
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "1")
+    env["WD_BENCH_LAUNCHER"] = "bench.py"
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=None, text=True, bufsize=1)
+    try:
+        for line in proc.stdout:
+            sys.stdout.write(line)
+            sys.stdout.flush()
+        return proc.wait()
+    except BaseException:
+        proc.terminate()          # exactly the child we started
+        try:
+            proc.wait(timeout=30)
+        except subprocess.TimeoutExpired:
+            proc.kill()
+        raise
 
 
 def traffic_lookup(key, tiles):
@@ -411,15 +461,19 @@ def e2e_probe(device, n_tiles, rows, cols, centre, lvl_off, nbr, cycles=50, thre
         shutil.rmtree(root, ignore_errors=True)
 
 
-def main():
-    args = parse()
+def main(argv=None):
+    argv = list(sys.argv[1:] if argv is None else argv)
+    args = parse(argv)
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # not under torchrun: this process becomes the launcher and never touches the GPU
+        sys.exit(launch_ranks(args, argv))
+    if args.dry_run:
+        print(json.dumps({"launcher": None, "note": "runs in this process (N = 1 or already under torchrun)"}))
+        return
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("launch with: python -m torch.distributed.run --nproc-per-node %d bench.py --gpus %d"
-                     % (args.gpus, args.gpus))
         args.gpus = world
 
     import torch
@@ -440,6 +494,19 @@ def main():
         else:
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
+    # proof that the process group holds N ranks: its own size, an all-reduce of ones through the
+    # backend the merge uses, and which device each rank sits on
+    ranks_seen = None
+    if use_dist:
+        ones = torch.ones(1, dtype=torch.int64, device="cpu" if rehearsal else torch.device("cuda", local_rank))
+        dist.all_reduce(ones)
+        where = [None] * dist.get_world_size()
+        dist.all_gather_object(where, {"rank": rank, "device": local_rank,
+                                       "gpu": torch.cuda.get_device_name(local_rank)})
+        ranks_seen = {"rccl_world": dist.get_world_size(), "allreduce_of_ones": int(ones.item()),
+                      "backend": dist.get_backend(), "launched_by": os.environ.get("WD_BENCH_LAUNCHER", "torchrun"),
+                      "ranks": where}
+
     from well_duplicates_amd import dist as wdist
     from well_duplicates_amd import synth, workload
     from well_duplicates_amd.scanner import Scanner, TileBatch, MODE_EQ, MODE_HAMMING, MODE_LEVENSHTEIN
@@ -455,7 +522,7 @@ def main():
     t0 = time.time()
     centre, lvl_off, nbr = workload.honeycomb_targets(rows, cols, T, levels, seed=13)
     spec = synth.SynthSpec(seed=2, n_clusters=n_clusters, row=cols)
-    lane = rank + 1
+    lane = args.first_lane + rank
     if args.stype is None:                                    # the layout BASELINE names for this N
         args.stype = "hiseq_x" if world == 1 else "hiseq_4000"
     tile_ids = [int(t) for t in workload.tiles_for_stype(args.stype)]
@@ -564,6 +631,8 @@ def main():
         fence()
     my_rows = block[rank * args.tiles:(rank + 1) * args.tiles]
     counts = block.cpu().numpy()
+    if rank == 0 and args.dump_block:
+        np.save(args.dump_block, counts)
     compares_all = int(counts[:, 1:1 + levels].sum())          # sum of Wells over every rank
     mine = counts[rank * args.tiles:(rank + 1) * args.tiles]
     compares_rank = int(mine[:, 1:1 + levels].sum())
@@ -757,7 +826,8 @@ def main():
         line = {
             "metric": "target x neighbour seq-compares/sec (whole node)",
             "value": round(value, 1), "unit": "compares/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "n_gpus": world, "rccl_world": None if ranks_seen is None else ranks_seen["rccl_world"],
+            "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 5), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u8", "data": "synthetic",
             "config": {"workload": "%d lane(s) x %d tiles (%s) x %d targets x %d levels, %d bp; one lane per GPU (%s)"
@@ -766,6 +836,7 @@ def main():
                        "clusters_per_tile": n_clusters, "compares_per_step": compares_all,
                        "valid_targets_per_rank": valid_rank, "parallelism": "tiles sharded, %d rank(s)" % world,
                        "merge": None if not use_dist else "one int64 all-reduce per %d step(s)" % chunk,
+                       "process_group": ranks_seen,
                        "setup_s": round(setup_s, 1)},
             "roofline": roofline,
             "cpu_baseline": cpu,

@@ -160,6 +160,27 @@ def test_cli_failing_rank_takes_the_others_down(tmp_path_factory, tmp_path):
     assert not os.path.exists(report_file) or open(report_file).read() == ""
 
 
+def test_cli_rank_that_fails_in_setup_takes_the_others_down(tmp_path_factory, tmp_path):
+    """Rank 1 cannot even create its context (without --device a rank takes GPU LOCAL_RANK, and this
+    box has one GPU): it never reaches the lane loop, yet rank 0 must not wait for it in the merge -
+    setup and scan feed the same failure flag."""
+    import time
+    fx, run_dir = _run_dir(tmp_path_factory, "mid")
+    run = fx["runs"][0]
+    argv = ["-f", os.path.join(GOLD, fx["targets_file"]), "-n", str(fx["n_targets"]),
+            "-l", str(fx["levels"]), "-s", fx.get("stype", "hiseq_4000"), "-r", run_dir,
+            "-t", ",".join(fx["tiles"]), "-i", ",".join(str(l) for l in fx["lanes"])]
+    report_file = str(tmp_path / "report.txt")
+    argv += run["flags"] + ["--dist-backend", "gloo", "-o", report_file, "-q"]
+    t0 = time.time()
+    res = _torchrun(argv, 2)
+    assert res.returncode != 0
+    assert time.time() - t0 < 120                      # (a rank left waiting would sit out the group's timeout)
+    err = res.stderr.decode()
+    assert "another rank failed" in err
+    assert not os.path.exists(report_file) or open(report_file).read() == ""
+
+
 def test_cli_missing_cycle_file_is_a_clean_error(tmp_path_factory):
     """A run folder that lacks one cycle's file of one tile: FileNotFoundError as in the reference
     (bcl_direct_reader.py:207-216) - raised only after every loader thread has finished, so

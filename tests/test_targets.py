@@ -192,3 +192,28 @@ def test_bulk_parser_refuses_what_is_not_regular(tmp_path):
     }.items():
         level = 4 if name == "too_few_rings" else 3
         assert load_targets_csr(_write(tmp_path, name + ".list", text), level) is None, name
+
+
+def test_malformed_tokens_raise_what_the_reference_raises(tmp_path):
+    """Tokens numpy's bulk parser would quietly read as numbers ('-' as 0, '0x10' as 0, '7abc' as
+    7, a stop at trailing garbage): the bulk parser must decline and the CLI's fallback -
+    load_targets, the reference's parser (target.py:31: int(x)) - raises ValueError."""
+    import pytest
+    from well_duplicates_amd.targets import load_targets, load_targets_csr
+    for name, text in {
+        "hex": "5\n1,2\n3,0x10\n",
+        "lone_minus": "5\n1,-\n3,4\n",
+        "trailing_garbage": "5\n1,2\n3,4q\n",
+        "garbage_mid": "5\n1,7abc\n3,4\n",
+        "plus_sign": "5\n1,+2\n3,4\n",            # int() takes it; the bulk parser leaves it to int()
+        "double_minus": "5\n1,--2\n3,4\n",
+        "float": "5\n1,2.0\n3,4\n",
+        "empty_token": "5\n1,,2\n3,4\n",
+    }.items():
+        f = _write(tmp_path, name + ".list", text)
+        assert load_targets_csr(f, 2) is None, name
+        if name == "plus_sign":
+            assert load_targets(f, levels=3).to_csr(2)[2].tolist() == [1, 2, 3, 4]
+        else:
+            with pytest.raises(ValueError):
+                load_targets(f, levels=3)

@@ -128,8 +128,16 @@ _T0 = [0.0]
 
 
 def default_threads() -> int:
-    """Reader threads (they read files into pinned memory; with --host-inflate they also gunzip)."""
-    return max(1, min(32, os.cpu_count() or 1))
+    """Reader threads (they read files into pinned memory; with --host-inflate they also gunzip):
+    at most 32, and under torchrun this rank's share of the host's CPUs - eight ranks of one node
+    read through one page cache and must not start 8 x 32 threads."""
+    cpus = os.cpu_count() or 1
+    try:
+        cpus = len(os.sched_getaffinity(0)) or cpus
+    except (AttributeError, OSError):
+        pass
+    local_world = max(1, int(os.environ.get("LOCAL_WORLD_SIZE", "1") or 1))
+    return max(1, min(32, cpus // local_world))
 
 
 def _lap(what: str):
@@ -363,7 +371,11 @@ def main(argv=None):
     levels = args.level
     out_fh = open(args.output, "w") if (args.output and rank == 0) else None
     try:
-        with Scanner(device) as sc:
+        # a rank whose setup fails (no memory on its GPU, a bad device, targets it cannot upload) must
+        # not leave the others waiting in the first collective: setup and scan feed ONE failure flag
+        sc, err = None, None
+        try:
+            sc = Scanner(device)
             if args.all_wells:
                 n_targets, n_slots = sc.targets_from_coords(xy[0], xy[1], None, levels=levels)
                 log("All %i wells are centres: %i neighbour slots in %i levels" % (n_targets, n_slots, levels))
@@ -372,6 +384,9 @@ def main(argv=None):
             else:
                 n_targets = n_parsed
                 sc.set_targets(*csr)
+        except Exception as e:              # noqa: BLE001 - re-raised below, on every rank
+            err = e
+        try:
             _lap("context, targets on the GPU")
             # (lane, tile) items are independent (count_well_duplicates.py:207-226): the flat list
             # is block-partitioned over the ranks, every rank scans its share lane by lane, and ONE
@@ -379,13 +394,14 @@ def main(argv=None):
             # lines) makes rank 0 hold what the single-process run holds
             lanes = list(lanes)
             items = [(lane, t) for lane in lanes for t in tiles]
+            pos = {item: i for i, item in enumerate(items)}
             mine = wdist.shard(items, rank, world)
             ncnt = 1 + 5 * levels
             rows = np.zeros((len(mine), ncnt), dtype=np.int64)
-            logs, err = {}, None
+            logs = {}
 
-            def emit(lane, block_of):       # a finished lane: its log lines, then its report (:269)
-                counts = {t: report.TileCounts.from_block(block_of(t), levels) for t in tiles}
+            def emit(lane, block):          # a finished lane: its log lines, then its report (:269)
+                counts = {t: report.TileCounts.from_block(block[pos[(lane, t)]], levels) for t in tiles}
                 for t in tiles:
                     for line in logs.get((lane, t), ()):
                         log(line)
@@ -393,23 +409,23 @@ def main(argv=None):
                                     strict=args.strict, out=out_fh)
 
             try:
-                for lane in lanes:
-                    lane_tiles = [t for (ln, t) in mine if ln == lane]
-                    if not lane_tiles:
+                for lane in lanes if err is None else ():
+                    mine_here = [i for i, (ln, _) in enumerate(mine) if ln == lane]
+                    if not mine_here:
                         continue
-                    counts, lane_logs = scan_lane(sc, reader, lane, lane_tiles, cycle_list, mode, k, csr, wells,
+                    counts, lane_logs = scan_lane(sc, reader, lane, [mine[i][1] for i in mine_here], cycle_list,
+                                                  mode, k, csr, wells,
                                                   max(0, args.tile_batch), args.threads,
                                                   0 if (args.quiet or args.all_wells) else len(cycles),
                                                   overlap=not args.serial_ingest,
                                                   interleave=4 if args.layout == "interleaved" else 1,
                                                   gpu_inflate=not args.host_inflate)
-                    for i, (ln, t) in enumerate(mine):
-                        if ln == lane:
-                            c = counts[t]
-                            rows[i] = [c.targets] + c.wells + c.dups + c.hit + c.first + c.last
+                    for i in mine_here:
+                        c = counts[mine[i][1]]
+                        rows[i] = [c.targets] + c.wells + c.dups + c.hit + c.first + c.last
                     logs.update({(lane, t): lines for t, lines in lane_logs.items()})
                     if world == 1:          # as the reference: a lane is reported when it is done
-                        emit(lane, lambda t: rows[items.index((lane, t))])
+                        emit(lane, rows)
             except Exception as e:          # noqa: BLE001 - re-raised below, on every rank
                 err = e
             if world > 1:
@@ -422,9 +438,12 @@ def main(argv=None):
                 logs = wdist.gather_dicts(logs, world)
                 if rank == 0:
                     for lane in lanes:
-                        emit(lane, lambda t: full[items.index((lane, t))])
+                        emit(lane, full)
             elif err is not None:
                 raise err
+        finally:
+            if sc is not None:
+                sc.close()
     finally:
         _lap("reports, context closed")
         if out_fh:

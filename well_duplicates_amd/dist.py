@@ -88,6 +88,8 @@ def merge_blocks(local_rows, n_items: int, rank: int, world: int, device=None, b
     import numpy as np
     lo, hi = shard_bounds(n_items, rank, world)
     if backend == "wd":
+        if world > 1 and scanner is None:
+            raise ValueError("backend 'wd' sums the block in the scanner's device memory: pass scanner=")
         rows = np.ascontiguousarray(local_rows, dtype=np.int64)
         assert rows.shape[0] == hi - lo
         full = np.zeros((n_items, rows.shape[1]), dtype=np.int64)

@@ -13,7 +13,12 @@ without a comma starts the next record.
 """
 from __future__ import annotations
 
+import re
+
 import numpy as np
+
+
+_REGULAR = re.compile(r"(?:-?[0-9]+[,\n])*(?:-?[0-9]+)?")
 
 
 class Target:
@@ -167,7 +172,10 @@ def load_targets_csr(filename, level, limit=None):
     then takes load_targets(), which raises what the reference raises (target.py:6-40, :72-78)."""
     with open(filename, "r") as fh:
         text = fh.read()
-    if not text or "\r" in text or " " in text or "\t" in text:
+    if not text or not _REGULAR.fullmatch(text):
+        # anything but decimal integers separated by single commas / newlines ('-' alone, '0x10',
+        # '7abc', blanks, '+5', '1_0' ...): numpy's bulk parser would read some of those as numbers
+        # where int() raises (target.py:31) - the reference's parser decides
         return None
     lines = text.split("\n")
     if lines[-1] == "":
