@@ -7,6 +7,7 @@ import zlib
 import numpy as np
 import pytest
 
+from helpers import REPO
 from well_duplicates_amd import synth
 from well_duplicates_amd.scanner import Scanner
 
@@ -401,4 +402,135 @@ def test_batches_from_several_threads(sc, tmp_path):
         for paths, dsts, want in sets:
             for d, w in zip(dsts, want):
                 assert (sc.d2h(d, n) == w).all()
+    sc.free(buf)
+
+
+def test_thread_creation_failure_is_an_error_code_not_an_abort(sc, tmp_path):
+    """The batch entry points start reader threads inside extern "C": a thread that cannot be started
+    must not end the caller's process (std::terminate).  `test_thread_limit` makes thread creation
+    fail after n threads per crew: with n >= 1 the batch is loaded by the threads there are, with 0
+    the call returns WD_ERR_NOMEM (MemoryError here) - and the context goes on working."""
+    n = 100001
+    spec = synth.SynthSpec(seed=5, n_clusters=n, row=333, qual_levels=7)
+    payloads = [synth.plane_bytes(spec, 1, 1101, c) for c in range(6)]
+    paths = []
+    for c, pl in enumerate(payloads):
+        p = tmp_path / ("c%d.bcl.gz" % c)
+        p.write_bytes(gzip.compress(synth.bcl_file_bytes(pl), 6))
+        paths.append(str(p))
+    junk = tmp_path / "multi.bcl.gz"                      # two members: the host loader's turn (second crew)
+    raw = synth.bcl_file_bytes(payloads[0])
+    junk.write_bytes(gzip.compress(raw[:5000]) + gzip.compress(raw[5000:]))
+    paths.append(str(junk))
+    stride = (n + 255) // 256 * 256
+    buf = sc.malloc(stride * len(paths) + 256)
+    dsts = [buf + i * stride for i in range(len(paths))]
+    try:
+        for limit in (2, 1):
+            sc.set_option("test_thread_limit", limit)
+            sc.memset(buf, 0xEE, stride * len(paths))
+            sc.load_bcl_gz_batch(paths, dsts, n, threads=256)
+            for i, pl in enumerate(payloads + [payloads[0]]):
+                assert (sc.d2h(dsts[i], n) == pl).all(), (limit, i)
+        sc.set_option("test_thread_limit", 0)
+        with pytest.raises(MemoryError):
+            sc.load_bcl_gz_batch(paths, dsts, n, threads=256)
+    finally:
+        sc.set_option("test_thread_limit", -1)
+    sc.load_bcl_gz_batch(paths, dsts, n, threads=256)      # 256 real threads, and the context still works
+    assert (sc.d2h(dsts[3], n) == payloads[3]).all()
+    sc.free(buf)
+
+
+def test_real_thread_limit_in_a_child_process(tmp_path):
+    """The same under a real RLIMIT_NPROC (an ordinary user's limit; root is exempt): the child loads a
+    batch with threads=256 while the limit leaves room for a few - it must exit by itself with an
+    answer (loaded, or an error code), never by abort."""
+    import subprocess
+    import sys
+    if os.geteuid() == 0:
+        pytest.skip("RLIMIT_NPROC does not bind root")
+    code = r'''
+import gzip, os, resource, sys
+sys.path.insert(0, %r)
+from well_duplicates_amd import synth
+from well_duplicates_amd.scanner import Scanner
+n = 50001
+spec = synth.SynthSpec(seed=5, n_clusters=n, row=333, qual_levels=7)
+paths = []
+for c in range(8):
+    p = os.path.join(%r, "c%%d.bcl.gz" %% c)
+    open(p, "wb").write(gzip.compress(synth.bcl_file_bytes(synth.plane_bytes(spec, 1, 1101, c)), 6))
+    paths.append(p)
+with Scanner(0) as sc:
+    stride = (n + 255) // 256 * 256
+    buf = sc.malloc(stride * 8 + 256)
+    dsts = [buf + i * stride for i in range(8)]
+    sc.load_bcl_gz_batch(paths, dsts, n, threads=4)          # the runtime's own threads exist now
+    uid = os.getuid()
+    mine = 0
+    for pid in os.listdir("/proc"):
+        if pid.isdigit():
+            try:
+                st = open("/proc/%%s/status" %% pid).read()
+            except OSError:
+                continue
+            if ("Uid:\t%%d" %% uid) in st:
+                mine += int(st.split("Threads:")[1].split()[0])
+    resource.setrlimit(resource.RLIMIT_NPROC, (mine + 3, resource.getrlimit(resource.RLIMIT_NPROC)[1]))
+    try:
+        sc.load_bcl_gz_batch(paths, dsts, n, threads=256)
+        ok = all((sc.d2h(dsts[c], n) == synth.plane_bytes(spec, 1, 1101, c)).all() for c in range(8))
+        print("LOADED" if ok else "WRONG")
+    except MemoryError:
+        print("ERROR CODE")
+''' % (REPO, str(tmp_path))
+    res = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0, (res.returncode, res.stderr[-2000:])
+    assert res.stdout.strip().splitlines()[-1] in ("LOADED", "ERROR CODE"), res.stdout
+
+
+def test_forged_cbcl_tile_count_is_a_format_error(sc, tmp_path):
+    """A .cbcl header whose tile count is absurd (4e9 tiles = a 64 GB table) is a format error
+    (AssertionError, as the reference's header asserts), not an allocation (bcl_direct_reader.py:274-286)."""
+    import struct
+    n = 1000
+    head = struct.pack("<HIBBI", 1, 5681, 2, 2, 4) + b"".join(struct.pack("<II", i, i) for i in range(4))
+    forged = tmp_path / "forged.cbcl"
+    forged.write_bytes(head + struct.pack("<I", 0xF0000000) + b"\0" * 6000)
+    buf = sc.malloc(4096)
+    for load in (lambda: sc.load_cbcl_batch([(str(forged), 1101, buf, buf + 2048)], n),
+                 lambda: sc.load_cbcl_tile(str(forged), 1101, buf, n, buf + 2048)):
+        with pytest.raises(AssertionError):
+            load()
+    sc.free(buf)
+
+
+def test_a_tiles_filter_error_comes_before_its_planes(sc, tmp_path):
+    """The reference opens a tile's .filter before its cycle files: when both are bad, the filter's
+    error is the one raised (bcl_direct_reader.py:124-132, :236 before :208)."""
+    n = 20001
+    spec = synth.SynthSpec(seed=5, n_clusters=n, row=333)
+    good = tmp_path / "good.bcl.gz"
+    good.write_bytes(gzip.compress(synth.bcl_file_bytes(synth.plane_bytes(spec, 1, 1101, 0)), 6))
+    junk = tmp_path / "junk.bcl.gz"
+    junk.write_bytes(b"not gzip at all" * 20)
+    okf = tmp_path / "ok.filter"
+    okf.write_bytes(synth.filter_file_bytes(synth.filter_bytes(spec, 1, 1101)))
+    badf = tmp_path / "bad.filter"
+    badf.write_bytes(synth.filter_file_bytes(synth.filter_bytes(spec, 1, 1101))[:-7])
+    stride = (n + 255) // 256 * 256
+    buf = sc.malloc(stride * 6)
+    d = [buf + i * stride for i in range(6)]
+    # tile 0: junk plane, good filter; tile 1: good plane, bad filter -> tile 0's plane error first
+    with pytest.raises(gzip.BadGzipFile):
+        sc.load_bcl_gz_batch([str(junk), str(good)], d[:2], n, filters=[(str(okf), d[2]), (str(badf), d[3])],
+                             tile_of=[0, 1, 0, 1])
+    # tile 0: junk plane AND bad filter -> the filter's assertion
+    with pytest.raises(AssertionError):
+        sc.load_bcl_gz_batch([str(junk), str(good)], d[:2], n, filters=[(str(badf), d[2]), (str(okf), d[3])],
+                             tile_of=[0, 1, 0, 1])
+    # without the map: filters first
+    with pytest.raises(AssertionError):
+        sc.load_bcl_gz_batch([str(junk), str(good)], d[:2], n, filters=[(str(okf), d[2]), (str(badf), d[3])])
     sc.free(buf)

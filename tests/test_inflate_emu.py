@@ -20,7 +20,10 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def emu(request, tmp_path_factory):
     waves, span, outdiv = request.param
     exe = str(tmp_path_factory.mktemp("emu") / ("inflate_emu_w%d_d%d" % (waves, outdiv)))
-    subprocess.check_call(["g++", "-O2", "-std=c++17", "-pthread", "-DEMU_WAVES=%d" % waves, "-DEMU_SPAN=%d" % span,
+    # CPU build only, under the sanitizers: out-of-bounds writes to the window, stage or match-list
+    # memory of a corrupt stream are findings here, not just crashes
+    subprocess.check_call(["g++", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined",
+                           "-std=c++17", "-pthread", "-DEMU_WAVES=%d" % waves, "-DEMU_SPAN=%d" % span,
                            "-DEMU_OUTDIV=%d" % outdiv, os.path.join(REPO, "tools", "inflate_emu.cpp"), "-lz", "-o", exe])
     return exe
 

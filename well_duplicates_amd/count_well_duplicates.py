@@ -247,7 +247,8 @@ def scan_lane(sc: Scanner, reader, lane, tiles, cycle_list, mode, k, csr, wells,
                 missing = sc.load_bcl_gz_batch([handles[i].plane_path(cycle_list[c]) for i, c in jobs],
                                                [tb.plane_ptr(i, c) for i, c in jobs], n_clusters,
                                                threads=max(1, threads), missing_ok=True, well_stride=interleave,
-                                               filters=[(h.filter_file, tb.filter_ptr(i)) for i, h in enumerate(handles)])
+                                               filters=[(h.filter_file, tb.filter_ptr(i)) for i, h in enumerate(handles)],
+                                               tile_of=[i for i, _ in jobs] + list(range(len(handles))))
                 for j in missing:           # (a run is .bcl.gz or .cbcl, never both: this loop is for the odd file)
                     load(*jobs[j])
             planes = [pool.submit(load_all)]

@@ -41,6 +41,9 @@
 #include <atomic>
 #include <chrono>
 #include <condition_variable>
+#include <functional>
+#include <new>
+#include <system_error>
 #include <memory>
 #include <mutex>
 #include <thread>
@@ -62,6 +65,7 @@ constexpr uint32_t kStatusEmptyLevel = 1u;
 
 #include "synth_kernels.inc"
 #include "scan_sequential.inc"
+#include "lev2_stream.inc"
 #include "scan_queue.inc"
 #include "scan_dense.inc"
 #include "scan_lev_generic.inc"
@@ -255,6 +259,8 @@ struct wd_ctx {
     size_t inflate_chunk_bytes = 16u << 20;            // option "inflate_chunk_mb" (pinning memory costs time: keep the ring small)
     InflateChunk inflate_chunks[kInflateChunks];
     size_t inflate_chunk_cap = 0;                      // bytes the chunks were allocated with
+    int lev2_closed = 1;                               // option: Levenshtein <= 2 by the closed form (0: banded DP)
+    long long test_thread_limit = -1;                  // option (tests): pretend thread creation fails after this many per crew
     int inflate_waves = 0;                             // option: waves per file (1, 4, 8; 0 = by the launch's size)
     hipStream_t inflate_streams[kInflateStreams + 1] = {};
     hipEvent_t inflate_ready[kInflateStreams] = {};    // a launch's files are all in the arena
@@ -518,6 +524,25 @@ int ensure_dense_tables(wd_ctx *ctx)
 template <bool STRIDED, int H>
 void launch_queue_lev(wd_ctx *ctx, const ScanArgs &a, dim3 grid)
 {
+    if constexpr (H == 1) {
+        // k = 2, the reference's default: the streaming closed form (lev2_stream.inc) instead of the
+        // banded DP - 8-byte queue entries, six waves per SIMD ("lev2_closed" = 0 keeps the DP: tests)
+        if (a.k == 2 && ctx->lev2_closed) {
+            const size_t lds2 = (size_t)scan_q_lds_dwords(a.levels, a.tpb, 2) * sizeof(uint32_t);
+            if constexpr (STRIDED) {
+                if (ctx->well_stride == 4) {
+                    hipLaunchKernelGGL((k_scan_q<true, 8, kLev2Closed, 4>), grid, dim3(kBlock), lds2, ctx->stream, a);
+                    return;
+                }
+            }
+            switch (ctx->queue_first) {
+            case 4: hipLaunchKernelGGL((k_scan_q<STRIDED, 4, kLev2Closed>), grid, dim3(kBlock), lds2, ctx->stream, a); break;
+            case 6: hipLaunchKernelGGL((k_scan_q<STRIDED, 6, kLev2Closed>), grid, dim3(kBlock), lds2, ctx->stream, a); break;
+            default: hipLaunchKernelGGL((k_scan_q<STRIDED, 5, kLev2Closed>), grid, dim3(kBlock), lds2, ctx->stream, a); break;
+            }
+            return;
+        }
+    }
     const size_t lds = (size_t)scan_q_lds_dwords(a.levels, a.tpb, 4) * sizeof(uint32_t);
     if constexpr (STRIDED && H == 1) {
         if (ctx->well_stride == 4) {                    // interleaved: the first round is two dwords per well
@@ -754,6 +779,12 @@ bool valid_batches(int b1, int b2)
 // -------------------------------------------------------------------------------------
 // C ABI
 // -------------------------------------------------------------------------------------
+// Every entry point that allocates on the host is a function-try-block: a C++ exception ends at the
+// boundary as an error code (a caller in C, ctypes or cgo cannot catch it: it would be std::terminate).
+#define WD_CATCH                                                                                  \
+    catch (const std::bad_alloc &) { return WD_ERR_NOMEM; }                                       \
+    catch (...) { return WD_ERR_STATE; }
+
 extern "C" {
 
 int wd_version(void) { return 100; }
@@ -800,7 +831,11 @@ wd_ctx *wd_create(int device_id)
         g_create_status = WD_ERR_ARG;
         return nullptr;
     }
-    wd_ctx *ctx = new wd_ctx();
+    wd_ctx *ctx = new (std::nothrow) wd_ctx();
+    if (!ctx) {
+        g_create_status = WD_ERR_NOMEM;
+        return nullptr;
+    }
     ctx->device = device_id;
     if (const char *fi = getenv("WD_FAST_INFLATE"))         // default of the "fast_inflate" option
         ctx->fast_inflate = atoi(fi) ? 1 : 0;
@@ -925,7 +960,7 @@ int wd_synchronize(wd_ctx *ctx)
 }
 
 int wd_set_option(wd_ctx *ctx, const char *name, int64_t value)
-{
+try {
     if (!ctx || !name)
         return WD_ERR_ARG;
     std::string n(name);
@@ -961,6 +996,10 @@ int wd_set_option(wd_ctx *ctx, const char *name, int64_t value)
         ctx->well_stride = (int)value;
     } else if (n == "fast_inflate") {
         ctx->fast_inflate = value ? 1 : 0;
+    } else if (n == "lev2_closed") {
+        ctx->lev2_closed = value ? 1 : 0;
+    } else if (n == "test_thread_limit") {
+        ctx->test_thread_limit = value;
     } else if (n == "inflate_waves") {
         if (value != 0 && value != 1 && value != 4 && value != 8)
             return WD_ERR_ARG;
@@ -989,10 +1028,10 @@ int wd_set_option(wd_ctx *ctx, const char *name, int64_t value)
         return fail(ctx, WD_ERR_ARG, "unknown option " + n);
     }
     return WD_OK;
-}
+} WD_CATCH
 
 int wd_get_option(wd_ctx *ctx, const char *name, int64_t *value)
-{
+try {
     if (!ctx || !name || !value)
         return WD_ERR_ARG;
     std::string n(name);
@@ -1011,6 +1050,8 @@ int wd_get_option(wd_ctx *ctx, const char *name, int64_t *value)
     else if (n == "fast_inflate") *value = ctx->fast_inflate;
     else if (n == "inflate_chunk_mb") *value = (long long)(ctx->inflate_chunk_bytes >> 20);
     else if (n == "inflate_waves") *value = ctx->inflate_waves;
+    else if (n == "test_thread_limit") *value = ctx->test_thread_limit;
+    else if (n == "lev2_closed") *value = ctx->lev2_closed;
     else if (n == "inflate_files_gpu") *value = ctx->inflate_files_gpu.load();
     else if (n == "inflate_files_host") *value = ctx->inflate_files_host.load();
     else if (n == "inflate_us_per_file") *value = ctx->inflate_us_per_file.load();
@@ -1024,10 +1065,10 @@ int wd_get_option(wd_ctx *ctx, const char *name, int64_t *value)
     else if (n == "dense_window_dwords") *value = ctx->win_dwords;
     else return fail(ctx, WD_ERR_ARG, "unknown option " + n);
     return WD_OK;
-}
+} WD_CATCH
 
 int wd_malloc(wd_ctx *ctx, size_t bytes, void **out_dev)
-{
+try {
     if (!ctx || !out_dev)
         return WD_ERR_ARG;
     if (bind_device(ctx))
@@ -1035,7 +1076,7 @@ int wd_malloc(wd_ctx *ctx, size_t bytes, void **out_dev)
     *out_dev = nullptr;
     WD_HIP(ctx, hipMalloc(out_dev, bytes ? bytes : 1));
     return WD_OK;
-}
+} WD_CATCH
 
 int wd_free(wd_ctx *ctx, void *dev)
 {
@@ -1082,7 +1123,7 @@ int wd_memset(wd_ctx *ctx, void *dst_dev, int value, size_t bytes)
 
 int wd_set_targets(wd_ctx *ctx, int T, int levels, const int32_t *centre, const int32_t *lvl_off,
                    const int32_t *nbr)
-{
+try {
     if (!ctx || T < 0 || levels < 0 || levels > kMaxLevels)
         return fail(ctx, WD_ERR_ARG, "bad T or levels");
     if (T > 0 && (!centre || !lvl_off))
@@ -1144,12 +1185,12 @@ int wd_set_targets(wd_ctx *ctx, int T, int levels, const int32_t *centre, const 
     set_group_bases(ctx, lvl_off, T, levels);
     ctx->has_targets = true;
     return WD_OK;
-}
+} WD_CATCH
 
 int wd_scan_async(wd_ctx *ctx, int n_tiles, int L, int mode, int k, const uint8_t *const *planes,
                   const uint8_t *const *filter, int64_t N, int64_t *out_tile_dev,
                   uint32_t *out_per_target_dev)
-{
+try {
     if (!ctx)
         return WD_ERR_ARG;
     if (!ctx->has_targets)
@@ -1367,7 +1408,7 @@ int wd_scan_async(wd_ctx *ctx, int n_tiles, int L, int mode, int k, const uint8_
         ctx->events.push_back(ev);
     }
     return WD_OK;
-}
+} WD_CATCH
 
 int wd_scan_status(wd_ctx *ctx)
 {
@@ -1386,7 +1427,7 @@ int wd_scan_status(wd_ctx *ctx)
 int wd_count_tiles(wd_ctx *ctx, int n_tiles, int L, int mode, int k, const uint8_t *const *planes,
                    const uint8_t *const *filter, int64_t N, int64_t *out_tile,
                    uint32_t *out_per_target)
-{
+try {
     if (!ctx || !out_tile)
         return WD_ERR_ARG;
     if (!ctx->has_targets)
@@ -1465,10 +1506,10 @@ int wd_count_tiles(wd_ctx *ctx, int n_tiles, int L, int mode, int k, const uint8
                                   (size_t)n_tiles * ctx->T * ctx->levels * sizeof(uint32_t), hipMemcpyDeviceToHost));
     }
     return WD_OK;
-}
+} WD_CATCH
 
 int wd_hitlog_enable(wd_ctx *ctx, int64_t capacity)
-{
+try {
     if (!ctx || capacity < 0)
         return WD_ERR_ARG;
     if (bind_device(ctx))
@@ -1483,10 +1524,10 @@ int wd_hitlog_enable(wd_ctx *ctx, int64_t capacity)
     }
     WD_HIP(ctx, hipMemsetAsync(ctx->d_hit_count, 0, sizeof(unsigned long long), ctx->stream));
     return WD_OK;
-}
+} WD_CATCH
 
 int wd_hitlog_fetch(wd_ctx *ctx, wd_hit *out_host, int64_t max_records, int64_t *total_out)
-{
+try {
     if (!ctx || max_records < 0)
         return WD_ERR_ARG;
     if (bind_device(ctx))
@@ -1500,7 +1541,7 @@ int wd_hitlog_fetch(wd_ctx *ctx, wd_hit *out_host, int64_t max_records, int64_t 
     if (n > 0 && out_host)
         WD_HIP(ctx, hipMemcpy(out_host, ctx->d_hits, (size_t)n * sizeof(wd_hit), hipMemcpyDeviceToHost));
     return WD_OK;
-}
+} WD_CATCH
 
 int wd_profile_get(wd_ctx *ctx, double *total_ms, int64_t *launches)
 {
@@ -1532,7 +1573,7 @@ int wd_profile_reset(wd_ctx *ctx)
 int wd_targets_from_coords(wd_ctx *ctx, const int32_t *x, const int32_t *y, int64_t n,
                            const int32_t *centres, int64_t n_centres, int levels,
                            const int32_t *max_dists, int64_t *P_out)
-{
+try {
     if (!ctx || !x || !y || n <= 0 || levels < 1 || levels > kMaxLevels || !max_dists)
         return fail(ctx, WD_ERR_ARG, "bad coordinates, levels or ring table");
     if (!centres)
@@ -1657,7 +1698,7 @@ int wd_targets_from_coords(wd_ctx *ctx, const int32_t *x, const int32_t *y, int6
     if (P_out)
         *P_out = P;
     return WD_OK;
-}
+} WD_CATCH
 
 int wd_targets_info(wd_ctx *ctx, int *T, int *levels, int64_t *P)
 {
@@ -1672,7 +1713,7 @@ int wd_targets_info(wd_ctx *ctx, int *T, int *levels, int64_t *P)
 }
 
 int wd_get_targets(wd_ctx *ctx, int32_t *centre, int32_t *lvl_off, int32_t *nbr)
-{
+try {
     if (!ctx)
         return WD_ERR_ARG;
     if (!ctx->has_targets)
@@ -1687,7 +1728,7 @@ int wd_get_targets(wd_ctx *ctx, int32_t *centre, int32_t *lvl_off, int32_t *nbr)
     if (nbr && ctx->P)
         WD_HIP(ctx, hipMemcpy(nbr, ctx->d_nbr, (size_t)ctx->P * 4, hipMemcpyDeviceToHost));
     return WD_OK;
-}
+} WD_CATCH
 
 // ---- ingest ---------------------------------------------------------------------------
 namespace {
@@ -1791,7 +1832,7 @@ int slot_reserve(wd_ctx *ctx, wd_ctx::IngestSlot *s, size_t need)
 }  // namespace
 
 int wd_interleave4(wd_ctx *ctx, const uint8_t *const src[4], int64_t n_clusters, uint8_t *dst_dev)
-{
+try {
     if (!ctx || !src || !dst_dev || n_clusters < 0)
         return WD_ERR_ARG;
     if (bind_device(ctx))
@@ -1801,10 +1842,10 @@ int wd_interleave4(wd_ctx *ctx, const uint8_t *const src[4], int64_t n_clusters,
                            ctx->stream, src[0], src[1], src[2], src[3], (long long)n_clusters, (uint32_t *)dst_dev);
     WD_HIP(ctx, hipGetLastError());
     return WD_OK;
-}
+} WD_CATCH
 
 int wd_gunzip(const uint8_t *src, size_t src_len, uint8_t *dst, size_t dst_cap, size_t *produced, int mode)
-{
+try {
     if (!src || !dst || !produced || (mode != 0 && mode != 1))
         return WD_ERR_ARG;
     *produced = 0;
@@ -1849,7 +1890,7 @@ int wd_gunzip(const uint8_t *src, size_t src_len, uint8_t *dst, size_t dst_cap, 
     *produced = (size_t)(zs.next_out - dst);
     inflateEnd(&zs);
     return rc;
-}
+} WD_CATCH
 
 // These two may be called from several host threads at once on one context (each call leases
 // its own pinned buffer and copy stream); they do not touch the context's error string.
@@ -1859,7 +1900,7 @@ int wd_load_bcl_gz(wd_ctx *ctx, const char *path, uint8_t *dst_dev, int64_t n_cl
 }
 
 int wd_load_bcl_gz_strided(wd_ctx *ctx, const char *path, uint8_t *dst_dev, int64_t n_clusters, int well_stride)
-{
+try {
     if (!ctx || !path || !dst_dev || n_clusters < 0 || (well_stride != 1 && well_stride != 4))
         return WD_ERR_ARG;
     if (hipSetDevice(ctx->device) != hipSuccess)
@@ -1965,7 +2006,7 @@ int wd_load_bcl_gz_strided(wd_ctx *ctx, const char *path, uint8_t *dst_dev, int6
             return WD_ERR_HIP;
     }
     return WD_OK;
-}
+} WD_CATCH
 
 // ---- a batch of .bcl.gz files through the GPU decoder ------------------------------------------
 namespace {
@@ -1974,6 +2015,64 @@ namespace {
 // order they arrived (so that batches a caller queued up are read in that order), one at a time.
 // The slot is chosen and locked while the turn is held: a slot's previous holder has had its turn
 // and only waits for the GPU, and no later call can take the slot first.
+extern "C++" {
+// Threads of one call: joined whichever way the call ends (an exception on the way out of an
+// extern "C" entry point must not meet a joinable std::thread: that is std::terminate).  A thread
+// that cannot be started (EAGAIN under a process limit, no memory) is not an error while one runs.
+struct Crew {
+    std::vector<std::thread> v;
+    std::function<void()> wake;                  // lets waiting threads go before the join of an unwind
+    template <class F>
+    int start(int want, F &fn, long long fail_after = -1)
+    {
+        int started = 0;
+        try {
+            v.reserve(v.size() + (size_t)std::max(want, 0));
+            for (int t = 0; t < want; t++) {
+                if (fail_after >= 0 && started >= fail_after)
+                    throw std::system_error(std::make_error_code(std::errc::resource_unavailable_try_again));
+                v.emplace_back(std::ref(fn));
+                started++;
+            }
+        } catch (const std::system_error &) {
+        } catch (const std::bad_alloc &) {
+        }
+        return started;
+    }
+    void join()
+    {
+        for (auto &t : v)
+            if (t.joinable())
+                t.join();
+        v.clear();
+    }
+    ~Crew()
+    {
+        if (!v.empty() && wake)
+            wake();
+        join();
+    }
+};
+
+// The body of an extern "C" entry point that allocates: C++ exceptions end here, as error codes.
+template <class F>
+int guarded(wd_ctx *ctx, F &&body)
+{
+    try {
+        return body();
+    } catch (const std::bad_alloc &) {
+        if (ctx)
+            (void)hipDeviceSynchronize();        // nothing of a failed call stays in flight
+        return WD_ERR_NOMEM;
+    } catch (...) {
+        if (ctx)
+            (void)hipDeviceSynchronize();
+        return WD_ERR_STATE;
+    }
+}
+
+}  // extern "C++"
+
 struct InflateTurn {
     wd_ctx *ctx;
     unsigned ticket;
@@ -2064,8 +2163,19 @@ int wd_load_bcl_gz_batch(wd_ctx *ctx, int n_files, const char *const *paths, uin
     return wd_load_tile_files_batch(ctx, n_files, paths, dst_dev, nullptr, n_clusters, 1, threads, rc_out);
 }
 
+static int load_tile_files_batch_impl(wd_ctx *ctx, int n_files, const char *const *paths, uint8_t *const *dst_dev,
+                                      const uint8_t *is_filter, int64_t n_clusters, int well_stride, int threads, int *rc_out);
+
 int wd_load_tile_files_batch(wd_ctx *ctx, int n_files, const char *const *paths, uint8_t *const *dst_dev,
                              const uint8_t *is_filter, int64_t n_clusters, int well_stride, int threads, int *rc_out)
+{
+    return guarded(ctx, [&] {
+        return load_tile_files_batch_impl(ctx, n_files, paths, dst_dev, is_filter, n_clusters, well_stride, threads, rc_out);
+    });
+}
+
+static int load_tile_files_batch_impl(wd_ctx *ctx, int n_files, const char *const *paths, uint8_t *const *dst_dev,
+                                      const uint8_t *is_filter, int64_t n_clusters, int well_stride, int threads, int *rc_out)
 {
     if (well_stride != 1 && well_stride != 4)
         return WD_ERR_ARG;
@@ -2181,9 +2291,14 @@ int wd_load_tile_files_batch(wd_ctx *ctx, int n_files, const char *const *paths,
             }
         }
     };
-    std::vector<std::thread> pool;
-    for (int t = 0; t < threads && t < std::max(1, n_files); t++)
-        pool.emplace_back(reader);
+    Crew pool;
+    pool.wake = [&] {
+        std::lock_guard<std::mutex> lk(mu);
+        abort_all = true;
+        cv.notify_all();
+    };
+    if (pool.start(std::min(threads, std::max(1, n_files)), reader, ctx->test_thread_limit) == 0)
+        return WD_ERR_NOMEM;                     // not one reader thread could be started
 
     // The chunks go to the arena one by one on the copy stream; a launch on the decode stream waits
     // for the copy of its last chunk (see kInflateLaunchFiles).
@@ -2305,8 +2420,7 @@ int wd_load_tile_files_batch(wd_ctx *ctx, int n_files, const char *const *paths,
         abort_all = true;
         cv.notify_all();
     }
-    for (auto &t : pool)
-        t.join();
+    pool.join();
     if (getenv("WD_INFLATE_STATS"))
         fprintf(stderr, "[wd inflate] chunk loop %.1f ms for %d chunks: waited %.1f ms for the readers, %.1f ms for chunk copies\n",
                 1e3 * std::chrono::duration<double>(std::chrono::steady_clock::now() - loop_t0).count(), n_groups,
@@ -2386,11 +2500,10 @@ int wd_load_tile_files_batch(wd_ctx *ctx, int n_files, const char *const *paths,
                                                           : wd_load_bcl_gz_strided(ctx, paths[i], dst_dev[i], n_clusters, well_stride);
             }
         };
-        std::vector<std::thread> hp;
-        for (int t = 0; t < threads && (size_t)t < todo.size(); t++)
-            hp.emplace_back(host);
-        for (auto &t : hp)
-            t.join();
+        Crew hp;
+        if (hp.start((int)std::min((size_t)threads, todo.size()) - 1, host, ctx->test_thread_limit) >= 0)
+            host();                              // this thread works too: the list is done even if none could be started
+        hp.join();
     }
     int first = WD_OK;
     for (int i = 0; i < n_files; i++) {
@@ -2403,7 +2516,7 @@ int wd_load_tile_files_batch(wd_ctx *ctx, int n_files, const char *const *paths,
 }
 
 int wd_load_filter(wd_ctx *ctx, const char *path, uint8_t *dst_dev, int64_t n_clusters)
-{
+try {
     if (!ctx || !path || !dst_dev || n_clusters < 0)
         return WD_ERR_ARG;
     if (hipSetDevice(ctx->device) != hipSuccess)
@@ -2431,11 +2544,11 @@ int wd_load_filter(wd_ctx *ctx, const char *path, uint8_t *dst_dev, int64_t n_cl
             return WD_ERR_HIP;
     }
     return WD_OK;
-}
+} WD_CATCH
 
 int wd_load_cbcl_tile(wd_ctx *ctx, const char *path, int tile_number, const uint8_t *filter_dev,
                       int64_t n_clusters, uint8_t *dst_dev)
-{
+try {
     if (!ctx || !path || !dst_dev || !filter_dev || n_clusters < 0)
         return WD_ERR_ARG;
     if (hipSetDevice(ctx->device) != hipSuccess)
@@ -2536,7 +2649,7 @@ int wd_load_cbcl_tile(wd_ctx *ctx, const char *path, int tile_number, const uint
     if (!excluded && n_records < n_clusters)
         return WD_ERR_INDEX;
     return WD_OK;
-}
+} WD_CATCH
 
 // ---- a batch of NovaSeq tile blocks through the GPU decoder -----------------------------------
 // Entry i: the block of tile tile_number[i] in the .cbcl file paths[i] (all tiles of a surface share
@@ -2547,9 +2660,22 @@ int wd_load_cbcl_tile(wd_ctx *ctx, const char *path, int tile_number, const uint
 // excluded-wells indirection through the tile's filter, which must already be in filter_dev[i]).
 // An entry the GPU decoder declines or whose checks fail (CRC-32, length) goes through
 // wd_load_cbcl_tile, whose return code is reported; so do the table checks' failures.
+static int load_cbcl_batch_impl(wd_ctx *ctx, int n, const char *const *paths, const int *tile_number,
+                                const uint8_t *const *filter_dev, uint8_t *const *dst_dev, int64_t n_clusters, int threads,
+                                int *rc_out);
+
 int wd_load_cbcl_batch(wd_ctx *ctx, int n, const char *const *paths, const int *tile_number,
                        const uint8_t *const *filter_dev, uint8_t *const *dst_dev, int64_t n_clusters, int threads,
                        int *rc_out)
+{
+    return guarded(ctx, [&] {
+        return load_cbcl_batch_impl(ctx, n, paths, tile_number, filter_dev, dst_dev, n_clusters, threads, rc_out);
+    });
+}
+
+static int load_cbcl_batch_impl(wd_ctx *ctx, int n, const char *const *paths, const int *tile_number,
+                                const uint8_t *const *filter_dev, uint8_t *const *dst_dev, int64_t n_clusters, int threads,
+                                int *rc_out)
 {
     if (!ctx || n < 0 || (n && (!paths || !tile_number || !filter_dev || !dst_dev)) || n_clusters < 0 ||
         n_clusters > 0x7FFFFFF0ll)
@@ -2609,9 +2735,14 @@ int wd_load_cbcl_batch(wd_ctx *ctx, int n, const char *const *paths, const int *
                         file_rc = WD_ERR_FORMAT;
                     } else {
                         memcpy(&tile_count, tab.data() + tab.size() - 4, 4);
-                        offs.resize((size_t)tile_count * 16 + 1);
-                        if (tile_count > (1u << 20) || fread(offs.data(), 1, offs.size(), f) != offs.size())
+                        if (tile_count > (1u << 20)) {                   // (before any allocation sized by it)
                             file_rc = WD_ERR_FORMAT;
+                            tile_count = 0;
+                        } else {
+                            offs.resize((size_t)tile_count * 16 + 1);
+                            if (fread(offs.data(), 1, offs.size(), f) != offs.size())
+                                file_rc = WD_ERR_FORMAT;
+                        }
                     }
                 }
                 fclose(f);
@@ -2726,9 +2857,14 @@ int wd_load_cbcl_batch(wd_ctx *ctx, int n, const char *const *paths, const int *
             }
         }
     };
-    std::vector<std::thread> pool;
-    for (int t = 0; t < threads && t < std::max(1, n); t++)
-        pool.emplace_back(reader);
+    Crew pool;
+    pool.wake = [&] {
+        std::lock_guard<std::mutex> lk(mu);
+        abort_all = true;
+        cv.notify_all();
+    };
+    if (pool.start(std::min(threads, std::max(1, n)), reader, ctx->test_thread_limit) == 0)
+        return WD_ERR_NOMEM;
     std::vector<int> job_file;
     job_file.reserve(n_jobs);
     int hip_rc = WD_OK;
@@ -2809,8 +2945,7 @@ int wd_load_cbcl_batch(wd_ctx *ctx, int n, const char *const *paths, const int *
         abort_all = true;
         cv.notify_all();
     }
-    for (auto &t : pool)
-        t.join();
+    pool.join();
     if (hip_rc == WD_OK && n_groups && hipEventRecord(slot.done, stream) != hipSuccess)
         hip_rc = WD_ERR_HIP;
     if (hip_rc != WD_OK)
@@ -2857,11 +2992,10 @@ int wd_load_cbcl_batch(wd_ctx *ctx, int n, const char *const *paths, const int *
                 rc[(size_t)i] = wd_load_cbcl_tile(ctx, paths[i], tile_number[i], filter_dev[i], n_clusters, dst_dev[i]);
             }
         };
-        std::vector<std::thread> hp;
-        for (int t = 0; t < threads && (size_t)t < todo.size(); t++)
-            hp.emplace_back(host);
-        for (auto &t : hp)
-            t.join();
+        Crew hp;
+        if (hp.start((int)std::min((size_t)threads, todo.size()) - 1, host, ctx->test_thread_limit) >= 0)
+            host();
+        hp.join();
     }
     int first = WD_OK;
     for (int i = 0; i < n; i++) {
@@ -2875,7 +3009,7 @@ int wd_load_cbcl_batch(wd_ctx *ctx, int n, const char *const *paths, const int *
 
 int wd_gather_wells(wd_ctx *ctx, const uint8_t *const *planes, int L, const int32_t *idx, int64_t n,
                     int64_t n_clusters, uint8_t *out_host)
-{
+try {
     if (!ctx || L < 0 || n < 0 || (n > 0 && L > 0 && (!planes || !idx || !out_host)))
         return fail(ctx, WD_ERR_ARG, "bad gather arguments");
     for (int64_t i = 0; i < n; i++)
@@ -2909,7 +3043,7 @@ int wd_gather_wells(wd_ctx *ctx, const uint8_t *const *planes, int L, const int3
         return done(WD_ERR_HIP, "gather kernel");
     (void)rc;
     return done(WD_OK, "");
-}
+} WD_CATCH
 
 // ---- RCCL ----------------------------------------------------------------------------
 int wd_comm_unique_id(void *out128)
@@ -2921,7 +3055,7 @@ int wd_comm_unique_id(void *out128)
 }
 
 int wd_comm_init(wd_ctx *ctx, int rank, int world, const void *id128)
-{
+try {
     if (!ctx || !id128 || world < 1 || rank < 0 || rank >= world)
         return WD_ERR_ARG;
     std::string err;
@@ -2940,7 +3074,7 @@ int wd_comm_init(wd_ctx *ctx, int rank, int world, const void *id128)
         return fail(ctx, WD_ERR_COMM, std::string("ncclCommInitRank: ") +
                                           (g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "?"));
     return WD_OK;
-}
+} WD_CATCH
 
 int wd_allreduce_counts(wd_ctx *ctx, int64_t *buf_dev, size_t n)
 {

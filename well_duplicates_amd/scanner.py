@@ -244,7 +244,8 @@ class Scanner:
             _raise(self._lib, None, rc, path)
 
     def load_bcl_gz_batch(self, paths: Sequence[str], dsts: Sequence[int], n_clusters: int, threads: int = 16,
-                          missing_ok: bool = False, filters: Sequence = (), well_stride: int = 1):
+                          missing_ok: bool = False, filters: Sequence = (), well_stride: int = 1,
+                          tile_of: Optional[Sequence[int]] = None):
         """Many .bcl.gz files -> device planes, inflated on the GPU (wd_load_bcl_gz_batch: host threads
         only read the compressed files; one wave per file decodes).  Raises what load_bcl_gz raises
         for the first file that fails; with missing_ok the files that do not exist are returned
@@ -259,16 +260,27 @@ class Scanner:
         c_dsts = (ctypes.c_void_p * max(1, n))(*[int(d) for d in dsts])
         kinds = (ctypes.c_uint8 * max(1, n))(*([0] * n_gz + [1] * (n - n_gz)))
         rcs = (ctypes.c_int * max(1, n))()
-        self._lib.wd_load_tile_files_batch(self._ctx, n, c_paths, c_dsts, kinds, int(n_clusters), int(well_stride),
-                                           int(threads), rcs)
+        rc = self._lib.wd_load_tile_files_batch(self._ctx, n, c_paths, c_dsts, kinds, int(n_clusters), int(well_stride),
+                                                int(threads), rcs)
+        if rc != _lib.OK and not any(rcs[i] != _lib.OK for i in range(n)):
+            _raise(self._lib, None, rc)         # the call itself failed (no memory, no thread, HIP), not a file
         missing = []
-        for i in range(n):
+        # which failure is reported: the reference meets a tile's .filter before that tile's cycle files
+        # (bcl_direct_reader.py:124-132, :195 before :200-216) and the tiles one after the other; with
+        # `tile_of` (tile of every plane, then of every filter) that order is kept, without it the
+        # filters come first
+        if tile_of is not None:
+            order = sorted(range(n), key=lambda i: (tile_of[i], i < n_gz, i))
+        else:
+            order = list(range(n_gz, n)) + list(range(n_gz))
+        for i in order:
             if rcs[i] == _lib.OK:
                 continue
             if rcs[i] == _lib.ERR_IO and missing_ok and i < n_gz:
                 missing.append(i)
                 continue
             _raise(self._lib, None, rcs[i], paths[i])
+        missing.sort()
         return missing
 
     def load_filter(self, path: str, dst: int, n_clusters: int):
@@ -293,10 +305,12 @@ class Scanner:
         c_filt = (ctypes.c_void_p * max(1, n))(*[int(e[2]) for e in entries])
         c_dst = (ctypes.c_void_p * max(1, n))(*[int(e[3]) for e in entries])
         rcs = (ctypes.c_int * max(1, n))()
-        self._lib.wd_load_cbcl_batch(self._ctx, n, c_paths, c_tiles, c_filt, c_dst, int(n_clusters), int(threads), rcs)
+        rc = self._lib.wd_load_cbcl_batch(self._ctx, n, c_paths, c_tiles, c_filt, c_dst, int(n_clusters), int(threads), rcs)
         for i in range(n):
             if rcs[i] != _lib.OK:
                 _raise(self._lib, None, rcs[i], entries[i][0])
+        if rc != _lib.OK:
+            _raise(self._lib, None, rc)         # the call itself failed, not an entry
 
     def gather_wells(self, plane_ptrs: Sequence[int], idx, n_clusters: int) -> np.ndarray:
         """uint8 [len(idx), L]: bytes of the given wells over the L planes."""
