@@ -292,6 +292,10 @@ int wd_hitlog_fetch(wd_ctx *ctx, wd_hit *out_host, int64_t max_records, int64_t 
  * around every n-th scan call): total milliseconds and timed launches since the last reset. */
 int wd_profile_get(wd_ctx *ctx, double *total_ms, int64_t *launches);
 int wd_profile_reset(wd_ctx *ctx);
+/* Template name of the compare kernel the last scan launched, as the code object spells it
+ * (e.g. "k_scan_q<true, 2, 0, 1>"; "" before the first scan): ties a counter profile of a kernel
+ * to the kernel a measurement really ran.  The string lives in the context. */
+const char *wd_last_kernel(const wd_ctx *ctx);
 
 /* ---- multi-GPU --------------------------------------------------------------------- */
 /*

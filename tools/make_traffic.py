@@ -3,6 +3,10 @@
 HBM bytes per scan (all kernels of one wd_scan_async) per tile, which bench.py reports as
 `roofline.traffic` / `other_modes.*.traffic` for the matching workload.
 
+These are L2-MISS bytes: FETCH_SIZE counts requests the L2 sent to the fabric, and the 256 MiB
+Infinity Cache sits behind it, so where a workload re-reads lines within a launch (or a bench loop
+rescans a resident lane) part of this traffic never reaches HBM.
+
 HBM bytes = 2 x FETCH_SIZE KiB (gfx950 tallies a 128-byte request as 64 B; calibrated for the
 byte-gather pattern in profiles/r01_b_*) + WRITE_SIZE KiB, per dispatch, summed over the scan's
 kernels (table builders and synthetic-data generators excluded).
@@ -18,8 +22,11 @@ SKIP = ("k_gen_rings", "k_transpose", "k_dense_windows", "k_synth", "k_interleav
 
 def main():
     out = {"_comment": __doc__.strip().replace("\n", " ")}
-    for path in sorted(glob.glob(os.path.join(REPO, "profiles", "r02_*_pmc_*.json"))):
+    # a later round's run of the same case replaces the earlier one (r03_* after r02_*)
+    for path in sorted(glob.glob(os.path.join(REPO, "profiles", "r0*_pmc_*.json"))):
         d = json.load(open(path))
+        if not d.get("probe"):
+            continue                                   # (round 1's summaries have another form)
         probe = next(iter(d["probe"].values()))
         tiles = probe["tiles"]
         kernels = {k: v for k, v in d["kernels"].items() if not k.startswith(SKIP) and "hbm_bytes_per_dispatch" in v}
@@ -30,7 +37,15 @@ def main():
         key = "%s_T%d_l%d_L%d" % (probe["case"], probe["T"], probe["levels"], probe["L"])
         if probe["workload"] == "dense":
             key += "_plant%d" % probe["plant_per_64k"]
-        out[key] = {"hbm_bytes_per_tile": total / tiles, "tiles_measured": tiles,
+        # the compare kernel the probe's library said it launched (wd_last_kernel; runs older than that
+        # entry point: the scan kernel's name as the profiler recorded it) - bench.py quotes these
+        # bytes only for a run whose library reports the same kernel
+        scan = [k for k in kernels if k.startswith(("k_scan_q<", "k_scan<"))]
+        kernel = probe.get("kernel") or (scan[0] if len(scan) == 1 else None)
+        if kernel is None and probe["workload"] == "dense":         # round 2's chain (kDenseChainVersion 2)
+            kernel = "dense chain v2, %s (k_dense_sig .. k_dense_reduce)" % (
+                {"dense_eq": "equality", "dense_ham2": "Hamming", "dense_lev2": "Levenshtein <= 2"}[probe["case"]])
+        out[key] = {"kernel": kernel, "hbm_bytes_per_tile": total / tiles, "tiles_measured": tiles,
                     "kernel_us_per_scan": round(dur, 1), "algorithmic_bytes_per_tile": probe["algorithmic_bytes"] / tiles,
                     "kernels": {k: round(v["hbm_bytes_per_dispatch"]) for k, v in sorted(kernels.items())},
                     "source": os.path.relpath(path, REPO)}

@@ -259,6 +259,7 @@ struct wd_ctx {
     size_t inflate_chunk_bytes = 16u << 20;            // option "inflate_chunk_mb" (pinning memory costs time: keep the ring small)
     InflateChunk inflate_chunks[kInflateChunks];
     size_t inflate_chunk_cap = 0;                      // bytes the chunks were allocated with
+    char last_kernel[96] = "";                         // template name of the compare kernel of the last scan
     int lev2_closed = 1;                               // option: Levenshtein <= 2 by the closed form (0: banded DP)
     long long test_thread_limit = -1;                  // option (tests): pretend thread creation fails after this many per crew
     int inflate_waves = 0;                             // option: waves per file (1, 4, 8; 0 = by the launch's size)
@@ -348,12 +349,22 @@ constexpr int kHamShapes[][2] = {{2, 4}, {3, 4}, {4, 4}, {4, 8}, {8, 8}};
 constexpr int lev_first(int H) { return H == 1 ? 7 : H == 2 ? 10 : H == 3 ? 13 : H == 4 ? 16 : H <= 6 ? 20 : 24; }
 constexpr int kLevB2 = 8;
 
+// One launch of the queue kernel; its template name - as the code object spells it - is kept for
+// wd_last_kernel(), so that a counter profile can be tied to the kernel that really ran.
+#define WD_LAUNCH_Q(STR, B1_, LEVH_, WS_, LDS_)                                                          \
+    do {                                                                                                 \
+        snprintf(ctx->last_kernel, sizeof(ctx->last_kernel), "k_scan_q<%s, %d, %d, %d>", (STR) ? "true" : "false", \
+                 (int)(B1_), (int)(LEVH_), (int)(WS_));                                                  \
+        hipLaunchKernelGGL((k_scan_q<(STR), (B1_), (LEVH_), (WS_)>), grid, dim3(kBlock), (LDS_), ctx->stream, a); \
+    } while (0)
+
 template <bool STRIDED>
 void launch_ham(wd_ctx *ctx, const ScanArgs &a, dim3 grid)
 {
     const int b1 = ctx->batch_first, b2 = ctx->batch_next;
 #define WD_CASE(B1, B2)                                                                   \
     if (b1 == B1 && b2 == B2) {                                                           \
+        snprintf(ctx->last_kernel, sizeof(ctx->last_kernel), "k_scan<HamState, %s, %d, %d>", STRIDED ? "true" : "false", B1, B2); \
         hipLaunchKernelGGL((k_scan<HamState, STRIDED, B1, B2>), grid, dim3(kBlock), 0,    \
                            ctx->stream, a);                                               \
         return;                                                                           \
@@ -369,6 +380,8 @@ void launch_ham(wd_ctx *ctx, const ScanArgs &a, dim3 grid)
 template <int H>
 void launch_lev(wd_ctx *ctx, const ScanArgs &a, dim3 grid, bool strided)
 {
+    snprintf(ctx->last_kernel, sizeof(ctx->last_kernel), "k_scan<LevState<%d>, %s, %d, %d>", H, strided ? "true" : "false",
+             lev_first(H), kLevB2);
     if (strided)
         hipLaunchKernelGGL((k_scan<LevState<H>, true, lev_first(H), kLevB2>), grid, dim3(kBlock), 0,
                            ctx->stream, a);
@@ -382,7 +395,7 @@ int launch_queue(wd_ctx *ctx, const ScanArgs &a, dim3 grid)
 {
     const size_t lds = (size_t)scan_q_lds_dwords(a.levels, a.tpb) * sizeof(uint32_t);
     if (STRIDED && ctx->well_stride == 4) {                 // interleaved: one dword = the first round
-        hipLaunchKernelGGL((k_scan_q<true, 4, 0, STRIDED ? 4 : 1>), grid, dim3(kBlock), lds, ctx->stream, a);
+        WD_LAUNCH_Q(true, 4, 0, STRIDED ? 4 : 1, lds);
         return 0;
     }
     // A random neighbour survives r cycles with <= k mismatches with probability
@@ -391,14 +404,14 @@ int launch_queue(wd_ctx *ctx, const ScanArgs &a, dim3 grid)
     if (first == 0)
         first = a.k <= 0 ? 2 : (a.k == 1 ? 3 : (a.k == 2 ? 5 : (a.k == 3 ? 6 : 8)));   // measured on MI355X
     switch (first) {
-    case 1: hipLaunchKernelGGL((k_scan_q<STRIDED, 1>), grid, dim3(kBlock), lds, ctx->stream, a); break;
-    case 2: hipLaunchKernelGGL((k_scan_q<STRIDED, 2>), grid, dim3(kBlock), lds, ctx->stream, a); break;
-    case 3: hipLaunchKernelGGL((k_scan_q<STRIDED, 3>), grid, dim3(kBlock), lds, ctx->stream, a); break;
-    case 4: hipLaunchKernelGGL((k_scan_q<STRIDED, 4>), grid, dim3(kBlock), lds, ctx->stream, a); break;
-    case 5: hipLaunchKernelGGL((k_scan_q<STRIDED, 5>), grid, dim3(kBlock), lds, ctx->stream, a); break;
-    case 6: hipLaunchKernelGGL((k_scan_q<STRIDED, 6>), grid, dim3(kBlock), lds, ctx->stream, a); break;
-    case 7: hipLaunchKernelGGL((k_scan_q<STRIDED, 7>), grid, dim3(kBlock), lds, ctx->stream, a); break;
-    default: hipLaunchKernelGGL((k_scan_q<STRIDED, 8>), grid, dim3(kBlock), lds, ctx->stream, a); break;
+    case 1: WD_LAUNCH_Q(STRIDED, 1, 0, 1, lds); break;
+    case 2: WD_LAUNCH_Q(STRIDED, 2, 0, 1, lds); break;
+    case 3: WD_LAUNCH_Q(STRIDED, 3, 0, 1, lds); break;
+    case 4: WD_LAUNCH_Q(STRIDED, 4, 0, 1, lds); break;
+    case 5: WD_LAUNCH_Q(STRIDED, 5, 0, 1, lds); break;
+    case 6: WD_LAUNCH_Q(STRIDED, 6, 0, 1, lds); break;
+    case 7: WD_LAUNCH_Q(STRIDED, 7, 0, 1, lds); break;
+    default: WD_LAUNCH_Q(STRIDED, 8, 0, 1, lds); break;
     }
     return 0;
 }
@@ -531,14 +544,14 @@ void launch_queue_lev(wd_ctx *ctx, const ScanArgs &a, dim3 grid)
             const size_t lds2 = (size_t)scan_q_lds_dwords(a.levels, a.tpb, 2) * sizeof(uint32_t);
             if constexpr (STRIDED) {
                 if (ctx->well_stride == 4) {
-                    hipLaunchKernelGGL((k_scan_q<true, 8, kLev2Closed, 4>), grid, dim3(kBlock), lds2, ctx->stream, a);
+                    WD_LAUNCH_Q(true, 8, kLev2Closed, 4, lds2);
                     return;
                 }
             }
             switch (ctx->queue_first) {
-            case 4: hipLaunchKernelGGL((k_scan_q<STRIDED, 4, kLev2Closed>), grid, dim3(kBlock), lds2, ctx->stream, a); break;
-            case 6: hipLaunchKernelGGL((k_scan_q<STRIDED, 6, kLev2Closed>), grid, dim3(kBlock), lds2, ctx->stream, a); break;
-            default: hipLaunchKernelGGL((k_scan_q<STRIDED, 5, kLev2Closed>), grid, dim3(kBlock), lds2, ctx->stream, a); break;
+            case 4: WD_LAUNCH_Q(STRIDED, 4, kLev2Closed, 1, lds2); break;
+            case 6: WD_LAUNCH_Q(STRIDED, 6, kLev2Closed, 1, lds2); break;
+            default: WD_LAUNCH_Q(STRIDED, 5, kLev2Closed, 1, lds2); break;
             }
             return;
         }
@@ -546,7 +559,7 @@ void launch_queue_lev(wd_ctx *ctx, const ScanArgs &a, dim3 grid)
     const size_t lds = (size_t)scan_q_lds_dwords(a.levels, a.tpb, 4) * sizeof(uint32_t);
     if constexpr (STRIDED && H == 1) {
         if (ctx->well_stride == 4) {                    // interleaved: the first round is two dwords per well
-            hipLaunchKernelGGL((k_scan_q<true, 8, 1, 4>), grid, dim3(kBlock), lds, ctx->stream, a);
+            WD_LAUNCH_Q(true, 8, 1, 4, lds);
             return;
         }
     }
@@ -559,9 +572,9 @@ void launch_queue_lev(wd_ctx *ctx, const ScanArgs &a, dim3 grid)
     constexpr int first_even = lev_first(H) - (H <= 2 ? 2 : 0), first_odd = lev_first(H) + 1 - (H == 1 ? 2 : 0);
     // an odd threshold (k = 2H + 1) keeps random neighbours alive about one cycle longer
     if (a.k & 1)
-        hipLaunchKernelGGL((k_scan_q<STRIDED, first_odd, H>), grid, dim3(kBlock), lds, ctx->stream, a);
+        WD_LAUNCH_Q(STRIDED, first_odd, H, 1, lds);
     else
-        hipLaunchKernelGGL((k_scan_q<STRIDED, first_even, H>), grid, dim3(kBlock), lds, ctx->stream, a);
+        WD_LAUNCH_Q(STRIDED, first_even, H, 1, lds);
 }
 
 // grow-only device scratch of the dense path
@@ -1365,6 +1378,8 @@ try {
         WD_HIP(ctx, hipEventRecord(ev.first, ctx->stream));
     }
     if (use_dense) {
+        snprintf(ctx->last_kernel, sizeof(ctx->last_kernel), "dense chain v%d, %s (k_dense_sig .. k_dense_reduce)",
+                 kDenseChainVersion, lev2 ? "Levenshtein <= 2" : (kk > 0 ? "Hamming" : "equality"));
         int rc = launch_dense(ctx, a, grid, n_tiles, N, strided, n_plane_ptrs, tile_chunk, lev2);
         if (rc)
             return rc;
@@ -1389,6 +1404,7 @@ try {
     } else if (lev_generic) {
         const int h = kk / 2;
         const size_t lds = lev_generic_lds_bytes(L, h);
+        snprintf(ctx->last_kernel, sizeof(ctx->last_kernel), "k_scan_lev_generic<%s>", strided ? "true" : "false");
         if (strided)
             hipLaunchKernelGGL((k_scan_lev_generic<true>), grid, dim3(kWave), lds, ctx->stream, a, h);
         else
@@ -1556,6 +1572,8 @@ int wd_profile_get(wd_ctx *ctx, double *total_ms, int64_t *launches)
         *launches = ctx->prof_launches;
     return WD_OK;
 }
+
+const char *wd_last_kernel(const wd_ctx *ctx) { return ctx ? ctx->last_kernel : ""; }
 
 int wd_profile_reset(wd_ctx *ctx)
 {

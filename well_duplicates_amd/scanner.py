@@ -353,6 +353,10 @@ class Scanner:
     def profile_reset(self):
         self._ck(self._lib.wd_profile_reset(self._ctx))
 
+    def last_kernel(self) -> str:
+        """Template name of the compare kernel the last scan launched (wd_last_kernel)."""
+        return self._lib.wd_last_kernel(self._ctx).decode()
+
     # ------------------------------------------------------------------ multi-GPU
     def comm_unique_id(self) -> bytes:
         buf = ctypes.create_string_buffer(_lib.UNIQUE_ID_BYTES)
