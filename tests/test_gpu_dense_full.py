@@ -94,3 +94,37 @@ def test_dense_path_vs_queue_kernel_on_the_whole_tile(setup):
             assert (blocks_to_reference(got_b[0], LEVELS) == ref).all(), name
     finally:
         sc.set_option("dense_kernel", -1)
+
+
+def test_part_pipeline_gives_the_same_answers(setup):
+    """Option dense_overlap: the scan as a pipeline of parts over two streams and two scratch sets
+    (launch_dense) - any part size, bounded or unbounded pack kernel - must give the one-chain scan's
+    tally blocks, per-target counts and hit records (with scan-wide tile numbers)."""
+    sc, tb1, spec, n = setup
+    tiles = 5
+    tb = TileBatch(sc, tiles, 40, n)
+    tb.fill_synthetic(spec, [(2, 1101 + i) for i in range(tiles)], list(range(40)))
+    try:
+        for mode, k, name in MODES:
+            sc.set_option("dense_overlap", 0)
+            sc.hitlog_enable(4_000_000)
+            want_b, want_pt = tb.count(mode, k, per_target=True)
+            want_hits, total = sc.hitlog_fetch(4_000_000)
+            assert 0 < total <= 4_000_000
+            want_hits = np.sort(want_hits, order=["tile", "target", "slot"])
+            assert set(np.unique(want_hits["tile"]).tolist()) == set(range(tiles))
+            for part, pack_blocks in ((0, 1024), (1, 0), (2, 64), (4, 1024)):
+                sc.set_option("dense_overlap", 1)
+                sc.set_option("dense_part_tiles", part)
+                sc.set_option("dense_pack_blocks", pack_blocks)
+                got_b, got_pt = tb.count(mode, k, per_target=True)
+                hits, total2 = sc.hitlog_fetch(4_000_000)
+                assert (got_b == want_b).all() and (got_pt == want_pt).all(), (name, part, pack_blocks)
+                assert total2 == total
+                assert (np.sort(hits, order=["tile", "target", "slot"]) == want_hits).all(), (name, part)
+    finally:
+        sc.hitlog_enable(0)
+        sc.set_option("dense_overlap", 0)
+        sc.set_option("dense_part_tiles", 0)
+        sc.set_option("dense_pack_blocks", 1024)
+        tb.free()

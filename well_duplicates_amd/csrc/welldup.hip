@@ -150,7 +150,14 @@ struct wd_ctx {
     uint32_t *d_qcnt = nullptr;                // dense path: entries used per block region
     size_t qcnt_cap = 0;
     long long dense_queue_cap = 0;             // option: entries per 256-target block; 0 = from k
-    uint32_t *d_cand = nullptr;                // dense path: survivor counts of the batch (kDenseSlots)
+    uint32_t *d_cand = nullptr;                // dense path: survivor flags of a part (kDenseSlots + 1), two sets
+    size_t cand_cap = 0;
+    hipStream_t dense_hi = nullptr, dense_lo = nullptr;   // dense path: compare stages (high priority) / pack stages
+    hipEvent_t dense_ev_start = nullptr, dense_ev_done = nullptr, dense_ev_cmp[2] = {nullptr, nullptr},
+               dense_ev_pack[2] = {nullptr, nullptr};
+    int dense_overlap = 0;                     // option: a dense scan as a pipeline of parts over two streams (measured: no gain, see launch_dense)
+    int dense_part_tiles = 0;                  // option: tiles per part (0 = by the scan's size)
+    int dense_pack_blocks = 1024;              // option: workgroups of the pack kernel beside a compare stage (0 = one per block of wells)
     uint4 *d_rows = nullptr;                   // dense path: packed cycles of the marked wells [n_tiles][N][kRowGroups]
     size_t rows_cap = 0;       // uint4 elements
     uint32_t *d_mark = nullptr;                // dense path: [3][n_tiles][mw_stride]: mark bits, word prefixes, block prefixes
@@ -613,16 +620,52 @@ bool dense_rows_reserve(wd_ctx *ctx, int n_tiles, int64_t N)
     return true;
 }
 
+// Tiles per part of a dense scan (launch_dense): two halves of a small scan, else as many tiles as
+// one compare-stage wave walks; the whole scan when the overlap is off.
+int dense_part_size(const wd_ctx *ctx, int n_tiles, int tile_chunk)
+{
+    if (!ctx->dense_overlap || n_tiles < 2)
+        return std::max(1, n_tiles);
+    if (ctx->dense_part_tiles > 0)
+        return std::min(ctx->dense_part_tiles, n_tiles);
+    return n_tiles >= 2 * tile_chunk ? tile_chunk : (n_tiles + 1) / 2;
+}
+
 // The dense path of wd_scan_async (scan_dense.inc): signatures, pairs, verify, reduce.
-int launch_dense(wd_ctx *ctx, const ScanArgs &a, dim3 grid, int n_tiles, int64_t N, bool strided,
-                 size_t n_plane_ptrs, int tile_chunk, bool lev2)
+//
+// By default the whole scan is one chain on the caller's stream.  Option "dense_overlap" = 1 runs it as
+// a pipeline of PARTS of a few tiles, each with one of two scratch sets: the chain of one part is
+// serial - the pack kernel needs the marks the compare stage leaves - but its two heavy kernels are
+// bound by different things (k_dense_pack streams 140 of the 150 planes: HBM; k_dense_pairs_win
+// compares from LDS: instruction issue), so the COMPARE stages (sig, counts, pairs, mark) of all parts
+// go one after the other on a high-priority stream of the context's own and the PACK stages (rank,
+// pack, verify, reduce) on a normal one, part c's pack stage after its compare stage, part c+2's
+// compare stage after part c's pack stage (it takes over the scratch set); "dense_pack_blocks" bounds
+// the pack kernel's footprint so that the compare stage finds wave slots beside it.
+// MEASURED (round 3, rocprofv3 traces in profiles/r03_b_dense_overlap_*): the kernels do run side by
+// side, and each pays for it - beside the pack kernel k_dense_sig takes 3 x, k_dense_counts 6 - 15 x
+// and k_dense_pairs_win 1.8 - 3 x as long (latency-bound kernels next to a kernel that keeps every HBM
+// queue full), so 16 tiles take 2.74 ms against 2.76 ms in one chain.  Hence the default.
+int launch_dense(wd_ctx *ctx, const ScanArgs &a, int n_tiles, int64_t N, bool strided, size_t n_plane_ptrs,
+                 int tile_chunk, bool lev2)
 {
     int rc = ensure_dense_tables(ctx);
     if (rc)
         return rc;
+    // parts: two halves of a small scan, else as many tiles as one compare-stage wave walks
+    const int part = dense_part_size(ctx, n_tiles, tile_chunk);
+    const int n_parts = (n_tiles + part - 1) / part;
+    const int n_sets = n_parts > 1 ? 2 : 1;
+    if (n_parts > 1 && !ctx->dense_hi) {
+        int least = 0, greatest = 0;
+        WD_HIP(ctx, hipDeviceGetStreamPriorityRange(&least, &greatest));
+        WD_HIP(ctx, hipStreamCreateWithPriority(&ctx->dense_hi, hipStreamNonBlocking, greatest));
+        WD_HIP(ctx, hipStreamCreateWithPriority(&ctx->dense_lo, hipStreamNonBlocking, least));
+        for (hipEvent_t *e : {&ctx->dense_ev_start, &ctx->dense_ev_done, &ctx->dense_ev_cmp[0], &ctx->dense_ev_cmp[1],
+                              &ctx->dense_ev_pack[0], &ctx->dense_ev_pack[1]})
+            WD_HIP(ctx, hipEventCreateWithFlags(e, hipEventDisableTiming));
+    }
     DenseArgs d;
-    d.planes = a.planes;
-    d.filter = a.filter;
     d.stride = a.stride;
     d.centre = a.centre;
     d.lvl_off = a.lvl_off;
@@ -640,15 +683,12 @@ int launch_dense(wd_ctx *ctx, const ScanArgs &a, dim3 grid, int n_tiles, int64_t
     d.kpad = ctx->win_kpad;
     d.win_dwords = ctx->win_dwords;
     d.gbase = ctx->d_gbase;
-    d.out_per_target = a.out_per_target;
     d.rare = a.rare;
     d.N = N;
     d.T = a.T;
     d.levels = a.levels;
     d.L = a.L;
     d.k = a.k;
-    d.n_tiles = n_tiles;
-    d.tile_chunk = tile_chunk;
     d.sig_cycles = std::min(kSigCycles, a.L);
     d.strided = strided ? 1 : 0;
     d.check_empty = a.check_empty;
@@ -661,121 +701,159 @@ int launch_dense(wd_ctx *ctx, const ScanArgs &a, dim3 grid, int n_tiles, int64_t
     // region holds mostly duplicate pairs; what does not fit is finished inside k_dense_pairs (or,
     // for Levenshtein, by k_dense_verify): a speed knob, not a limit
     const long long n_groups = (a.T + kWave - 1) / kWave;
-    const long long regions = (long long)n_tiles * n_groups;
     long long q_per = ctx->dense_queue_cap > 0 ? ctx->dense_queue_cap : (lev2 ? 32 : 16);
     // LDS of a k_dense_pairs wave: its signature windows, then 8 bytes per queue entry
     const long long win_bytes = (long long)kWinBufs * d.win_dwords * sizeof(uint32_t);
     q_per = std::max<long long>(1, std::min<long long>(q_per, kWave));      // one queue entry per lane at most
     d.q_per = (int)q_per;
     d.mw_stride = (((N + 31) / 32) + kMarkBlock - 1) / kMarkBlock * kMarkBlock;
-    const size_t mark_words = (size_t)n_tiles * d.mw_stride;
-    const size_t part_need = (size_t)n_tiles * kDenseSlots * d.partial_stride;
-    const size_t mask_need = (size_t)n_tiles * d.mask_stride;
-    if ((rc = dense_reserve(ctx, ctx->d_sig, ctx->sig_cap, (size_t)d.sig_stride * n_tiles * ((lev2 || a.k > 0) ? 2 : 1), "signature planes")) ||
-        (rc = dense_reserve(ctx, ctx->d_partial, ctx->partial_cap, part_need, "counter slots")) ||
-        (rc = dense_reserve(ctx, ctx->d_mask, ctx->mask_cap, mask_need, "hit masks")) ||
-        (rc = dense_reserve(ctx, ctx->d_queue, ctx->queue_cap, (size_t)(regions * q_per), "survivor queue")) ||
-        (rc = dense_reserve(ctx, ctx->d_qcnt, ctx->qcnt_cap, (size_t)regions, "survivor counts")) ||
-        (rc = dense_reserve(ctx, ctx->d_mark, ctx->mark_cap, 3 * mark_words, "marked wells")))
+    // scratch of ONE part (the largest); set s of a buffer starts s parts in
+    const size_t sig_words = (size_t)d.sig_stride * part * ((lev2 || a.k > 0) ? 2 : 1);
+    const size_t mark_words = (size_t)part * d.mw_stride;
+    const size_t part_need = (size_t)part * kDenseSlots * d.partial_stride;
+    const size_t mask_need = (size_t)part * d.mask_stride;
+    const size_t regions = (size_t)part * (size_t)n_groups;
+    const size_t cand_words = (kDenseSlots + 1 + 31) & ~(size_t)31;
+    if ((rc = dense_reserve(ctx, ctx->d_sig, ctx->sig_cap, sig_words * n_sets, "signature planes")) ||
+        (rc = dense_reserve(ctx, ctx->d_partial, ctx->partial_cap, part_need * n_sets, "counter slots")) ||
+        (rc = dense_reserve(ctx, ctx->d_mask, ctx->mask_cap, mask_need * n_sets, "hit masks")) ||
+        (rc = dense_reserve(ctx, ctx->d_queue, ctx->queue_cap, regions * (size_t)q_per * n_sets, "survivor queue")) ||
+        (rc = dense_reserve(ctx, ctx->d_qcnt, ctx->qcnt_cap, regions * n_sets, "survivor counts")) ||
+        (rc = dense_reserve(ctx, ctx->d_mark, ctx->mark_cap, 3 * mark_words * n_sets, "marked wells")) ||
+        (rc = dense_reserve(ctx, ctx->d_cand, ctx->cand_cap, cand_words * 2, "survivor flags")))
         return rc;
-    d.mark = ctx->d_mark;
-    d.wprefix = ctx->d_mark + mark_words;
-    d.bprefix = ctx->d_mark + 2 * mark_words;
-    if (!ctx->d_cand)
-        WD_HIP(ctx, hipMalloc((void **)&ctx->d_cand, (kDenseSlots + 1) * sizeof(uint32_t)));
     // packed rows are optional scratch (64 bytes per well): without them every survivor is
     // checked against the planes
-    d.rows = nullptr;
     d.pack_mode = ctx->dense_pack;
     d.lev2 = lev2 ? 1 : 0;
     d.nbr = a.nbr;
-    if ((d.pack_mode != 0 || lev2) && a.L > d.sig_cycles && a.L <= 40 * kRowGroups &&
-        dense_rows_reserve(ctx, n_tiles, N))
-        d.rows = ctx->d_rows;
-    if (lev2 && a.L > d.sig_cycles && !d.rows)               // (the caller reserved them)
+    const bool want_rows = (d.pack_mode != 0 || lev2) && a.L > d.sig_cycles && a.L <= 40 * kRowGroups &&
+                           dense_rows_reserve(ctx, part * n_sets, N);
+    if (lev2 && a.L > d.sig_cycles && !want_rows)            // (the caller reserved them)
         return fail(ctx, WD_ERR_NOMEM, "packed rows");
     // Checking one survivor against the planes touches 2 (L - 10) cache lines, one per plane and
     // well; packing touches at most one line per plane and MARKED well (wells of a line share it,
     // lines without a marked well are skipped) and leaves a 64-byte row per marked well: never
     // more lines than the byte-by-byte check, so rows are used whenever there is a survivor
     // (dense_packed, scan_dense.inc).
-    d.cand = ctx->d_cand;
-    WD_HIP(ctx, hipMemsetAsync(ctx->d_cand, 0, (kDenseSlots + 1) * sizeof(uint32_t), ctx->stream));
-    d.sig = ctx->d_sig;
-    // distances > 0: the compare stage reads 16-cycle screen words (k_dense_sig)
-    d.sig2 = (lev2 || a.k > 0) ? ctx->d_sig + (size_t)d.sig_stride * n_tiles : nullptr;
-    d.partial = ctx->d_partial;
-    d.mask = ctx->d_mask;
-    d.queue = ctx->d_queue;
-    d.q_cnt = ctx->d_qcnt;
-    WD_HIP(ctx, hipMemsetAsync(ctx->d_partial, 0, part_need * sizeof(unsigned long long), ctx->stream));
-    WD_HIP(ctx, hipMemsetAsync(ctx->d_mask, 0, mask_need * sizeof(uint32_t), ctx->stream));
-    if (d.rows)
-        WD_HIP(ctx, hipMemsetAsync(ctx->d_mark, 0, mark_words * sizeof(uint32_t), ctx->stream));
 
     // dword loads in k_dense_sig need every plane 4-byte aligned
     bool aligned4 = (a.stride & 3) == 0;
     for (size_t i = 0; i < n_plane_ptrs && aligned4; i++)
         aligned4 = ((uintptr_t)ctx->h_tbl[i] & 3u) == 0;
-    const dim3 grid4((unsigned)((N + 4ll * kBlock - 1) / (4ll * kBlock)), (unsigned)n_tiles);
-    const dim3 grid1((unsigned)((N + kBlock - 1) / kBlock), (unsigned)n_tiles);
-    if (aligned4 && strided)
-        hipLaunchKernelGGL((k_dense_sig<true, true>), grid4, dim3(kBlock), 0, ctx->stream, d);
-    else if (aligned4)
-        hipLaunchKernelGGL((k_dense_sig<true, false>), grid4, dim3(kBlock), 0, ctx->stream, d);
-    else if (strided)
-        hipLaunchKernelGGL((k_dense_sig<false, true>), grid1, dim3(kBlock), 0, ctx->stream, d);
-    else
-        hipLaunchKernelGGL((k_dense_sig<false, false>), grid1, dim3(kBlock), 0, ctx->stream, d);
-    // LDS of a compare-stage wave: its windows, one queue per tile of the chunk, their counts
-    const size_t q_lds = (size_t)kWaves * ((size_t)win_bytes + 4 * ((size_t)tile_chunk * (2 * d.q_per + 1) + (tile_chunk & 1)));
-    hipLaunchKernelGGL(k_dense_counts, dim3((unsigned)((a.T + 4 * kBlock - 1) / (4 * kBlock)),
-                                            (unsigned)((n_tiles + tile_chunk - 1) / tile_chunk)),
-                       dim3(kBlock), 0, ctx->stream, d);
     const int pmode = lev2 ? 2 : (a.k == 0 ? 0 : 1);
+    const unsigned mark_blocks = (unsigned)((n_groups + kWave * kWaves - 1) / (kWave * kWaves));
+    const long long dense_bpt = (a.T + kBlock - 1) / kBlock;
+    // st: the compare stage's stream, sp: the pack stage's
+    hipStream_t st = n_parts > 1 ? ctx->dense_hi : ctx->stream, sp = n_parts > 1 ? ctx->dense_lo : ctx->stream;
+    if (n_parts > 1) {
+        WD_HIP(ctx, hipEventRecord(ctx->dense_ev_start, ctx->stream));
+        WD_HIP(ctx, hipStreamWaitEvent(st, ctx->dense_ev_start, 0));
+        WD_HIP(ctx, hipStreamWaitEvent(sp, ctx->dense_ev_start, 0));
+    }
+    for (int c = 0; c < n_parts; c++) {
+        const int t0 = c * part, nt = std::min(part, n_tiles - t0), set = c & 1;
+        if (c >= 2)                                 // the scratch set is free when part c - 2 has been verified
+            WD_HIP(ctx, hipStreamWaitEvent(st, ctx->dense_ev_pack[set], 0));
+        const int tc = std::max(1, std::min(tile_chunk, nt));
+        d.planes = a.planes + (strided ? (size_t)t0 : (size_t)t0 * a.L);
+        d.filter = a.filter + t0;
+        d.out_per_target = a.out_per_target ? a.out_per_target + (size_t)t0 * a.T * a.levels : nullptr;
+        d.tile0 = t0;
+        d.n_tiles = nt;
+        d.tile_chunk = tc;
+        d.sig = ctx->d_sig + sig_words * set;
+        // distances > 0: the compare stage reads 16-cycle screen words (k_dense_sig)
+        d.sig2 = (lev2 || a.k > 0) ? d.sig + (size_t)d.sig_stride * nt : nullptr;
+        d.partial = ctx->d_partial + part_need * set;
+        d.mask = ctx->d_mask + mask_need * set;
+        d.queue = ctx->d_queue + regions * (size_t)q_per * set;
+        d.q_cnt = ctx->d_qcnt + regions * set;
+        d.mark = ctx->d_mark + 3 * mark_words * set;
+        d.wprefix = d.mark + (size_t)nt * d.mw_stride;
+        d.bprefix = d.mark + 2 * (size_t)nt * d.mw_stride;
+        d.cand = ctx->d_cand + cand_words * set;
+        d.rows = want_rows ? ctx->d_rows + (size_t)part * (size_t)N * kRowGroups * set : nullptr;
+        WD_HIP(ctx, hipMemsetAsync(d.cand, 0, (kDenseSlots + 1) * sizeof(uint32_t), st));
+        WD_HIP(ctx, hipMemsetAsync(d.partial, 0, (size_t)nt * kDenseSlots * d.partial_stride * sizeof(unsigned long long), st));
+        WD_HIP(ctx, hipMemsetAsync(d.mask, 0, (size_t)nt * d.mask_stride * sizeof(uint32_t), st));
+        if (d.rows)
+            WD_HIP(ctx, hipMemsetAsync(d.mark, 0, (size_t)nt * d.mw_stride * sizeof(uint32_t), st));
+        const dim3 grid((unsigned)((long long)kXcds * ((dense_bpt + kXcds - 1) / kXcds) * ((nt + tc - 1) / tc)));
+        const dim3 grid4((unsigned)((N + 4ll * kBlock - 1) / (4ll * kBlock)), (unsigned)nt);
+        const dim3 grid1((unsigned)((N + kBlock - 1) / kBlock), (unsigned)nt);
+        if (aligned4 && strided)
+            hipLaunchKernelGGL((k_dense_sig<true, true>), grid4, dim3(kBlock), 0, st, d);
+        else if (aligned4)
+            hipLaunchKernelGGL((k_dense_sig<true, false>), grid4, dim3(kBlock), 0, st, d);
+        else if (strided)
+            hipLaunchKernelGGL((k_dense_sig<false, true>), grid1, dim3(kBlock), 0, st, d);
+        else
+            hipLaunchKernelGGL((k_dense_sig<false, false>), grid1, dim3(kBlock), 0, st, d);
+        // LDS of a compare-stage wave: its windows, one queue per tile of the chunk, their counts
+        const size_t q_lds = (size_t)kWaves * ((size_t)win_bytes + 4 * ((size_t)tc * (2 * d.q_per + 1) + (tc & 1)));
+        hipLaunchKernelGGL(k_dense_counts, dim3((unsigned)((a.T + 4 * kBlock - 1) / (4 * kBlock)), (unsigned)((nt + tc - 1) / tc)),
+                           dim3(kBlock), 0, st, d);
 #define WD_LAUNCH_PAIRS(MODE)                                                                                   \
     do {                                                                                                        \
         if (d.ginfo)                                                                                            \
-            hipLaunchKernelGGL((k_dense_pairs_win<MODE>), grid, dim3(kBlock), q_lds, ctx->stream, d);           \
+            hipLaunchKernelGGL((k_dense_pairs_win<MODE>), grid, dim3(kBlock), q_lds, st, d);                    \
         if (ctx->n_window_groups < n_groups || !d.ginfo) {                                                      \
             if (ctx->nbr_t16)                                                                                   \
-                hipLaunchKernelGGL((k_dense_pairs<MODE, true>), grid, dim3(kBlock), q_lds, ctx->stream, d);    \
+                hipLaunchKernelGGL((k_dense_pairs<MODE, true>), grid, dim3(kBlock), q_lds, st, d);             \
             else                                                                                                \
-                hipLaunchKernelGGL((k_dense_pairs<MODE, false>), grid, dim3(kBlock), q_lds, ctx->stream, d);  \
+                hipLaunchKernelGGL((k_dense_pairs<MODE, false>), grid, dim3(kBlock), q_lds, st, d);           \
         }                                                                                                       \
     } while (0)
-    if (pmode == 0)
-        WD_LAUNCH_PAIRS(0);
-    else if (pmode == 1)
-        WD_LAUNCH_PAIRS(1);
-    else
-        WD_LAUNCH_PAIRS(2);
-#undef WD_LAUNCH_PAIRS
-    const unsigned mark_blocks = (unsigned)((n_groups + kWave * kWaves - 1) / (kWave * kWaves));
-    if (lev2)
-        hipLaunchKernelGGL(k_dense_mark, dim3(mark_blocks, (unsigned)n_tiles), dim3(kBlock), 0, ctx->stream, d);
-    if (d.rows) {
-        hipLaunchKernelGGL(k_dense_rank_words, dim3((unsigned)(d.mw_stride / kMarkBlock), (unsigned)n_tiles), dim3(kMarkBlock),
-                           0, ctx->stream, d);
-        hipLaunchKernelGGL(k_dense_rank_blocks, dim3((unsigned)n_tiles), dim3(1024), 0, ctx->stream, d);
-        if (aligned4 && strided && ctx->dense_nt)
-            hipLaunchKernelGGL((k_dense_pack<4, true, true>), grid4, dim3(kBlock), 0, ctx->stream, d);
-        else if (aligned4 && strided)
-            hipLaunchKernelGGL((k_dense_pack<4, true>), grid4, dim3(kBlock), 0, ctx->stream, d);
-        else if (aligned4)
-            hipLaunchKernelGGL((k_dense_pack<4, false>), grid4, dim3(kBlock), 0, ctx->stream, d);
-        else if (strided)
-            hipLaunchKernelGGL((k_dense_pack<1, true>), grid1, dim3(kBlock), 0, ctx->stream, d);
+        if (pmode == 0)
+            WD_LAUNCH_PAIRS(0);
+        else if (pmode == 1)
+            WD_LAUNCH_PAIRS(1);
         else
-            hipLaunchKernelGGL((k_dense_pack<1, false>), grid1, dim3(kBlock), 0, ctx->stream, d);
+            WD_LAUNCH_PAIRS(2);
+#undef WD_LAUNCH_PAIRS
+        if (lev2)
+            hipLaunchKernelGGL(k_dense_mark, dim3(mark_blocks, (unsigned)nt), dim3(kBlock), 0, st, d);
+        if (n_parts > 1) {                          // compared: the pack stage may start, the next part's compare stage does
+            WD_HIP(ctx, hipEventRecord(ctx->dense_ev_cmp[set], st));
+            WD_HIP(ctx, hipStreamWaitEvent(sp, ctx->dense_ev_cmp[set], 0));
+        }
+        if (d.rows) {
+            hipLaunchKernelGGL(k_dense_rank_words, dim3((unsigned)(d.mw_stride / kMarkBlock), (unsigned)nt), dim3(kMarkBlock), 0, sp, d);
+            hipLaunchKernelGGL(k_dense_rank_blocks, dim3((unsigned)nt), dim3(1024), 0, sp, d);
+            // with a compare stage beside it the pack kernel gets a bounded footprint: dense_pack_blocks
+            // workgroups in all (they walk their tiles with a stride), not one per kBlock * VEC wells
+            dim3 pg4 = grid4, pg1 = grid1;
+            if (n_parts > 1 && ctx->dense_pack_blocks > 0) {
+                const unsigned per_tile = (unsigned)std::max(1, ctx->dense_pack_blocks / nt);
+                pg4.x = std::min(pg4.x, per_tile);
+                pg1.x = std::min(pg1.x, per_tile);
+            }
+            if (aligned4 && strided && ctx->dense_nt)
+                hipLaunchKernelGGL((k_dense_pack<4, true, true>), pg4, dim3(kBlock), 0, sp, d);
+            else if (aligned4 && strided)
+                hipLaunchKernelGGL((k_dense_pack<4, true>), pg4, dim3(kBlock), 0, sp, d);
+            else if (aligned4)
+                hipLaunchKernelGGL((k_dense_pack<4, false>), pg4, dim3(kBlock), 0, sp, d);
+            else if (strided)
+                hipLaunchKernelGGL((k_dense_pack<1, true>), pg1, dim3(kBlock), 0, sp, d);
+            else
+                hipLaunchKernelGGL((k_dense_pack<1, false>), pg1, dim3(kBlock), 0, sp, d);
+        }
+        const dim3 vgrid(kXcds * ((mark_blocks + kXcds - 1) / kXcds), (unsigned)nt);
+        if (strided)
+            hipLaunchKernelGGL((k_dense_verify<true>), vgrid, dim3(kBlock), 0, sp, d);
+        else
+            hipLaunchKernelGGL((k_dense_verify<false>), vgrid, dim3(kBlock), 0, sp, d);
+        hipLaunchKernelGGL(k_dense_reduce, dim3(nt), dim3(kWave), 0, sp, d.partial, d.partial_stride, 1 + 5 * a.levels,
+                           a.out_tile + (size_t)t0 * (1 + 5 * a.levels));
+        if (n_parts > 1)
+            WD_HIP(ctx, hipEventRecord(ctx->dense_ev_pack[set], sp));
     }
-    const dim3 vgrid(kXcds * ((mark_blocks + kXcds - 1) / kXcds), (unsigned)n_tiles);
-    if (strided)
-        hipLaunchKernelGGL((k_dense_verify<true>), vgrid, dim3(kBlock), 0, ctx->stream, d);
-    else
-        hipLaunchKernelGGL((k_dense_verify<false>), vgrid, dim3(kBlock), 0, ctx->stream, d);
-    hipLaunchKernelGGL(k_dense_reduce, dim3(n_tiles), dim3(kWave), 0, ctx->stream, ctx->d_partial,
-                       d.partial_stride, 1 + 5 * a.levels, a.out_tile);
+    if (n_parts > 1) {                              // the caller's stream has it all behind it
+        WD_HIP(ctx, hipEventRecord(ctx->dense_ev_done, sp));     // (every compare stage lies before some pack stage)
+        WD_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->dense_ev_done, 0));
+    }
     return WD_OK;
 }
 
@@ -907,6 +985,15 @@ void wd_destroy(wd_ctx *ctx)
     (void)hipFree(ctx->d_queue);
     (void)hipFree(ctx->d_qcnt);
     (void)hipFree(ctx->d_cand);
+    for (hipStream_t q : {ctx->dense_hi, ctx->dense_lo})
+        if (q) {
+            (void)hipStreamSynchronize(q);
+            (void)hipStreamDestroy(q);
+        }
+    for (hipEvent_t e : {ctx->dense_ev_start, ctx->dense_ev_done, ctx->dense_ev_cmp[0], ctx->dense_ev_cmp[1],
+                         ctx->dense_ev_pack[0], ctx->dense_ev_pack[1]})
+        if (e)
+            (void)hipEventDestroy(e);
     (void)hipFree(ctx->d_rows);
     (void)hipFree(ctx->d_gbase);
     (void)hipHostFree(ctx->h_status);
@@ -1009,6 +1096,16 @@ try {
         ctx->well_stride = (int)value;
     } else if (n == "fast_inflate") {
         ctx->fast_inflate = value ? 1 : 0;
+    } else if (n == "dense_overlap") {
+        ctx->dense_overlap = value ? 1 : 0;
+    } else if (n == "dense_pack_blocks") {
+        if (value < 0 || value > (1 << 24))
+            return WD_ERR_ARG;
+        ctx->dense_pack_blocks = (int)value;
+    } else if (n == "dense_part_tiles") {
+        if (value < 0 || value > 65535)
+            return WD_ERR_ARG;
+        ctx->dense_part_tiles = (int)value;
     } else if (n == "lev2_closed") {
         ctx->lev2_closed = value ? 1 : 0;
     } else if (n == "test_thread_limit") {
@@ -1065,6 +1162,9 @@ try {
     else if (n == "inflate_waves") *value = ctx->inflate_waves;
     else if (n == "test_thread_limit") *value = ctx->test_thread_limit;
     else if (n == "lev2_closed") *value = ctx->lev2_closed;
+    else if (n == "dense_overlap") *value = ctx->dense_overlap;
+    else if (n == "dense_part_tiles") *value = ctx->dense_part_tiles;
+    else if (n == "dense_pack_blocks") *value = ctx->dense_pack_blocks;
     else if (n == "inflate_files_gpu") *value = ctx->inflate_files_gpu.load();
     else if (n == "inflate_files_host") *value = ctx->inflate_files_host.load();
     else if (n == "inflate_us_per_file") *value = ctx->inflate_us_per_file.load();
@@ -1339,12 +1439,16 @@ try {
                           levels <= 8 && kk <= 2 && kk >= 0 &&    // levels: 8-bit hit masks
                           n_tiles <= 65535;                        // tiles ride in gridDim.y
     bool use_dense = dense_ok && (ctx->dense_kernel == 1 || (ctx->dense_kernel < 0 && ctx->T >= 65536));
-    if (use_dense && lev2 && L > kSigCycles && !dense_rows_reserve(ctx, n_tiles, N))
-        use_dense = false;                                   // no room for the rows: queue kernel
+    const int tile_chunk = std::max(1, std::min({ctx->dense_tile_chunk, n_tiles, 16}));    // (LDS: one survivor queue per tile)
+    if (use_dense && lev2 && L > kSigCycles) {
+        // rows for the parts in flight (two scratch sets), not for the whole scan
+        const int part = dense_part_size(ctx, n_tiles, tile_chunk);
+        if (!dense_rows_reserve(ctx, part * (part < n_tiles ? 2 : 1), N))
+            use_dense = false;                               // no room for the rows: queue kernel
+    }
     if (ws == 4 && ctx->dense_kernel < 0)
         use_dense = false;                                   // the dense path reads planes
     const int chunks = (ctx->T + ctx->tpb - 1) / ctx->tpb;
-    const int tile_chunk = std::max(1, std::min({ctx->dense_tile_chunk, n_tiles, 16}));    // (LDS: one survivor queue per tile)
     // dense grid: 8 XCDs x (target blocks per XCD) x tile_chunk x (chunks of tiles), see k_dense_pairs
     const long long dense_bpt = (ctx->T + kBlock - 1) / kBlock;
     const long long dense_blocks = (long long)kXcds * ((dense_bpt + kXcds - 1) / kXcds) *
@@ -1380,7 +1484,7 @@ try {
     if (use_dense) {
         snprintf(ctx->last_kernel, sizeof(ctx->last_kernel), "dense chain v%d, %s (k_dense_sig .. k_dense_reduce)",
                  kDenseChainVersion, lev2 ? "Levenshtein <= 2" : (kk > 0 ? "Hamming" : "equality"));
-        int rc = launch_dense(ctx, a, grid, n_tiles, N, strided, n_plane_ptrs, tile_chunk, lev2);
+        int rc = launch_dense(ctx, a, n_tiles, N, strided, n_plane_ptrs, tile_chunk, lev2);
         if (rc)
             return rc;
     } else if (use_queue) {
