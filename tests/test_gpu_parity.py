@@ -218,6 +218,65 @@ def test_kernel_variants_agree(sc):
     tb.free()
 
 
+def test_sorted_view_of_the_targets(sc):
+    """The queue kernels walk the targets sorted by centre (by column strip, then by well), workgroups
+    dealt out so that each XCD takes a contiguous stretch of (tile, chunk) pairs - with a grid that is
+    not a multiple of 8 here.  Whatever the order: the same tally blocks, the same per-target counts at
+    the targets' positions IN THE FILE, the same hit records (target = index in the file, slot =
+    position in the file's neighbour list).  File order, plain well order, strips of several widths;
+    targets given as CSR and targets generated on the device for sampled centres."""
+    from well_duplicates_amd import cluster_indexes
+    rows, cols, levels, L = 150, 700, 4, 30
+    n = rows * cols
+    x, y = synth.honeycomb_pixels(rows, cols)
+    spec = synth.SynthSpec(seed=91, n_clusters=n, row=cols, plant_per_64k=12000, nocall_per_64k=1500)
+    tiles = [(1, 1101), (1, 1102), (3, 2103)]
+    tb = TileBatch(sc, len(tiles), L, n)
+    tb.fill_synthetic(spec, tiles, list(range(L)))
+    centres = np.random.default_rng(17).permutation(n)[:1501].astype(np.int32)      # file order = random
+    try:
+        for how in ("generated", "csr"):
+            results = {}
+            for sort_targets, strip in ((0, 256), (1, 0), (1, 64), (1, 256), (1, 350)):
+                sc.set_option("sort_strip", strip)             # (read when the targets are installed)
+                if how == "generated":
+                    sc.targets_from_coords(x, y, centres, levels=levels)
+                    csr = sc.get_targets()
+                else:
+                    sc.set_targets(*csr)
+                assert (sc.get_targets()[0] == centres).all()              # the file's order is what the caller sees
+                sc.set_option("sort_targets", sort_targets)
+                for tpb in (64, 7):                                        # 24 x 3 = 72 and 215 x 3 = 645 workgroups
+                    sc.set_option("targets_per_block", tpb)
+                    for mode, k in ((0, 0), (1, 2), (2, 2), (2, 3)):
+                        sc.hitlog_enable(200000)
+                        blocks, pt = tb.count(mode, k, per_target=True)
+                        hits, total = sc.hitlog_fetch(200000)
+                        assert 0 < total <= 200000
+                        hits = np.sort(hits, order=["tile", "target", "slot"])
+                        key = (mode, k)
+                        if key not in results:
+                            results[key] = (blocks, pt, hits)
+                            # the file-order run against the oracle: one tile, per target
+                            if mode == 2 and k == 2:
+                                planes = [synth.plane_bytes(spec, 1, 1102, c) for c in range(L)]
+                                valid, dups, lens, _ = oracle.count_tile(planes, synth.filter_bytes(spec, 1, 1102), *csr, mode, k)
+                                got = pt[1].astype(np.int64)
+                                got[got == INVALID_TARGET] = -1
+                                assert (got == np.where(valid[:, None] == 1, dups, -1)).all()
+                        else:
+                            b0, p0, h0 = results[key]
+                            assert (blocks == b0).all() and (pt == p0).all(), (how, sort_targets, strip, tpb, mode, k)
+                            assert (hits == h0).all(), (how, sort_targets, strip, tpb, mode, k)
+    finally:
+        sc.hitlog_enable(0)
+        sc.set_option("sort_targets", 1)
+        sc.set_option("sort_strip", 256)
+        for name, v in DEFAULT_OPTIONS:
+            sc.set_option(name, v)
+        tb.free()
+
+
 @pytest.mark.parametrize("kind", ["all_nocall", "all_copies"])
 def test_low_diversity_stress(sc, kind):
     """Worst case for the early exit: (nearly) every neighbour equals its centre, so nothing

@@ -267,6 +267,11 @@ struct wd_ctx {
     InflateChunk inflate_chunks[kInflateChunks];
     size_t inflate_chunk_cap = 0;                      // bytes the chunks were allocated with
     char last_kernel[96] = "";                         // template name of the compare kernel of the last scan
+    // the queue kernel's view of the targets: sorted by centre well, so that targets whose neighbourhoods
+    // share cache lines sit in the same workgroup (install_sorted_view); null = the file's order is sorted
+    int32_t *d_centre_q = nullptr, *d_lvl_off_q = nullptr, *d_perm = nullptr;
+    int sort_targets = 1;                              // option: use it (0: file order, as rounds 1 and 2)
+    int sort_strip = 256;                              // option: width of the column strips of that order (0: plain well order)
     int lev2_closed = 1;                               // option: Levenshtein <= 2 by the closed form (0: banded DP)
     long long test_thread_limit = -1;                  // option (tests): pretend thread creation fails after this many per crew
     int inflate_waves = 0;                             // option: waves per file (1, 4, 8; 0 = by the launch's size)
@@ -397,6 +402,16 @@ void launch_lev(wd_ctx *ctx, const ScanArgs &a, dim3 grid, bool strided)
                            ctx->stream, a);
 }
 
+// the queue kernels read the targets sorted by centre (install_sorted_view)
+void queue_view(const wd_ctx *ctx, ScanArgs &a)
+{
+    if (ctx->sort_targets && ctx->d_perm) {
+        a.centre = ctx->d_centre_q;
+        a.lvl_off = ctx->d_lvl_off_q;
+        a.perm = ctx->d_perm;
+    }
+}
+
 template <bool STRIDED>
 int launch_queue(wd_ctx *ctx, const ScanArgs &a, dim3 grid)
 {
@@ -421,6 +436,81 @@ int launch_queue(wd_ctx *ctx, const ScanArgs &a, dim3 grid)
     default: WD_LAUNCH_Q(STRIDED, 8, 0, 1, lds); break;
     }
     return 0;
+}
+
+// The queue kernels walk the targets in the order of their centre wells, not in file order: a sampled
+// targets file is a random permutation of the tile (prepare_cluster_indexes.py:26-30, random.sample), and
+// neighbourhoods of different targets overlap - on the bench workload a third of the (plane, line) pairs a
+// scan touches are touched by two targets or more.  Sorted, those targets sit in the same workgroup or
+// the next one (which the block mapping of k_scan_q puts on the same XCD), and the second touch is an
+// L2 hit instead of an HBM line.  Only `centre` and the rows of `lvl_off` are permuted (the rows hold
+// absolute offsets into nbr, which stays as it is); perm[sorted position] = target's index in the file,
+// for the per-target output and the hit log.  Tallies are sums: order-free.
+//
+// The order is by column strip, then by well: strips of `sort_strip` wells (four cache lines) of the
+// tile's rows, whose length is read off the targets themselves (row_length_of).  In plain well order
+// the targets that share lines with a target - those within a few rows AND a line's width of columns -
+// are spread over the 20 nearest targets of the order, most of them in other columns; within a strip
+// they are the next one or two, in flight at the same time, and the shared line is still in the L2.
+int install_sorted_view(wd_ctx *ctx, const int32_t *centre, const int32_t *lvl_off, int T, int levels, long long row_len)
+{
+    (void)hipFree(ctx->d_centre_q);
+    (void)hipFree(ctx->d_lvl_off_q);
+    (void)hipFree(ctx->d_perm);
+    ctx->d_centre_q = ctx->d_lvl_off_q = ctx->d_perm = nullptr;
+    if (T < 2 || T >= 65536 * 64)              // (every well a centre: the dense path's business, and sorted as it is)
+        return WD_OK;
+    const long long strip = ctx->sort_strip > 0 && row_len >= 2ll * ctx->sort_strip ? ctx->sort_strip : 0;
+    auto key = [&](int32_t t) -> long long {
+        const long long c = centre[t];
+        return strip ? ((c % row_len) / strip) * (1ll << 40) + c : c;
+    };
+    bool sorted = true;
+    for (int t = 1; t < T && sorted; t++)
+        sorted = key(t - 1) <= key(t);
+    if (sorted)
+        return WD_OK;
+    const size_t row = (size_t)levels + 1;
+    std::vector<int32_t> perm((size_t)T), c2((size_t)T), o2((size_t)T * row);
+    for (int t = 0; t < T; t++)
+        perm[(size_t)t] = t;
+    std::stable_sort(perm.begin(), perm.end(), [&](int32_t a, int32_t b) { return key(a) < key(b); });
+    for (int t = 0; t < T; t++) {
+        c2[(size_t)t] = centre[perm[(size_t)t]];
+        memcpy(&o2[(size_t)t * row], lvl_off + (size_t)perm[(size_t)t] * row, row * sizeof(int32_t));
+    }
+    WD_HIP(ctx, hipMalloc((void **)&ctx->d_centre_q, (size_t)T * sizeof(int32_t)));
+    WD_HIP(ctx, hipMalloc((void **)&ctx->d_lvl_off_q, (size_t)T * row * sizeof(int32_t)));
+    WD_HIP(ctx, hipMalloc((void **)&ctx->d_perm, (size_t)T * sizeof(int32_t)));
+    WD_HIP(ctx, hipMemcpy(ctx->d_centre_q, c2.data(), (size_t)T * sizeof(int32_t), hipMemcpyHostToDevice));
+    WD_HIP(ctx, hipMemcpy(ctx->d_lvl_off_q, o2.data(), (size_t)T * row * sizeof(int32_t), hipMemcpyHostToDevice));
+    WD_HIP(ctx, hipMemcpy(ctx->d_perm, perm.data(), (size_t)T * sizeof(int32_t), hipMemcpyHostToDevice));
+    return WD_OK;
+}
+
+// Wells per row of the tile, as the targets show it: a target's nearest neighbours that are not beside
+// it in its own row lie one row up or down, about a row's length away in index (prepare_cluster_indexes.py
+// bins by distance on the honeycomb).  The median over a few hundred targets; 0 if they do not say.
+long long row_length_of(const int32_t *centre, const int32_t *lvl_off, const int32_t *nbr, int T, int levels)
+{
+    if (!nbr || levels < 1)
+        return 0;
+    std::vector<long long> est;
+    const size_t row = (size_t)levels + 1;
+    for (int t = 0; t < T && est.size() < 512; t++) {
+        long long best = 0;
+        for (int32_t p = lvl_off[(size_t)t * row]; p < lvl_off[(size_t)t * row + 1]; p++) {
+            const long long d = llabs((long long)nbr[p] - centre[t]);
+            if (d > 8 && (best == 0 || d < best))
+                best = d;
+        }
+        if (best)
+            est.push_back(best);
+    }
+    if (est.size() < 8)
+        return 0;
+    std::nth_element(est.begin(), est.begin() + (long)est.size() / 2, est.end());
+    return est[est.size() / 2];
 }
 
 // Group bases of the transposed neighbour table from host-side ring offsets (row = levels+1).
@@ -985,6 +1075,9 @@ void wd_destroy(wd_ctx *ctx)
     (void)hipFree(ctx->d_queue);
     (void)hipFree(ctx->d_qcnt);
     (void)hipFree(ctx->d_cand);
+    (void)hipFree(ctx->d_centre_q);
+    (void)hipFree(ctx->d_lvl_off_q);
+    (void)hipFree(ctx->d_perm);
     for (hipStream_t q : {ctx->dense_hi, ctx->dense_lo})
         if (q) {
             (void)hipStreamSynchronize(q);
@@ -1106,6 +1199,12 @@ try {
         if (value < 0 || value > 65535)
             return WD_ERR_ARG;
         ctx->dense_part_tiles = (int)value;
+    } else if (n == "sort_targets") {
+        ctx->sort_targets = value ? 1 : 0;
+    } else if (n == "sort_strip") {
+        if (value < 0 || value > (1 << 20))
+            return WD_ERR_ARG;
+        ctx->sort_strip = (int)value;            // (takes effect with the next set of targets)
     } else if (n == "lev2_closed") {
         ctx->lev2_closed = value ? 1 : 0;
     } else if (n == "test_thread_limit") {
@@ -1162,6 +1261,8 @@ try {
     else if (n == "inflate_waves") *value = ctx->inflate_waves;
     else if (n == "test_thread_limit") *value = ctx->test_thread_limit;
     else if (n == "lev2_closed") *value = ctx->lev2_closed;
+    else if (n == "sort_targets") *value = ctx->sort_targets;
+    else if (n == "sort_strip") *value = ctx->sort_strip;
     else if (n == "dense_overlap") *value = ctx->dense_overlap;
     else if (n == "dense_part_tiles") *value = ctx->dense_part_tiles;
     else if (n == "dense_pack_blocks") *value = ctx->dense_pack_blocks;
@@ -1296,6 +1397,8 @@ try {
     for (int t = 0; t < T; t++)
         ctx->k_max = std::max<int64_t>(ctx->k_max, (int64_t)lvl_off[(size_t)t * row + levels] - lvl_off[(size_t)t * row]);
     set_group_bases(ctx, lvl_off, T, levels);
+    if (int rc = install_sorted_view(ctx, centre, lvl_off, T, levels, row_length_of(centre, lvl_off, nbr, T, levels)))
+        return rc;
     ctx->has_targets = true;
     return WD_OK;
 } WD_CATCH
@@ -1410,6 +1513,7 @@ try {
     a.nbr = ctx->d_nbr;
     a.out_tile = (unsigned long long *)out_tile_dev;
     a.out_per_target = out_per_target_dev;
+    a.perm = nullptr;
     {
         ScanRare r{ctx->d_status, ctx->hit_cap > 0 ? ctx->d_hits : nullptr, ctx->d_hit_count,
                    (long long)ctx->hit_cap};
@@ -1488,6 +1592,7 @@ try {
         if (rc)
             return rc;
     } else if (use_queue) {
+        queue_view(ctx, a);
         if (strided)
             launch_queue<true>(ctx, a, grid);
         else
@@ -1502,6 +1607,7 @@ try {
         // Levenshtein <= k, k = 2..7 (the reference's default is 2): queue kernel, DP state in
         // the queue entries
         const int h = kk / 2;
+        queue_view(ctx, a);
         if (h <= 1) { if (strided) launch_queue_lev<true, 1>(ctx, a, grid); else launch_queue_lev<false, 1>(ctx, a, grid); }
         else if (h == 2) { if (strided) launch_queue_lev<true, 2>(ctx, a, grid); else launch_queue_lev<false, 2>(ctx, a, grid); }
         else { if (strided) launch_queue_lev<true, 3>(ctx, a, grid); else launch_queue_lev<false, 3>(ctx, a, grid); }
@@ -1816,6 +1922,16 @@ try {
         ctx->k_max = std::max<int64_t>(ctx->k_max, (int64_t)off[(size_t)t * (levels + 1) + levels] -
                                                         off[(size_t)t * (levels + 1)]);
     set_group_bases(ctx, off.data(), T, levels);
+    if (centres) {
+        // (the rows of the table: wells at the first well's height)
+        long long row_len = 0;
+        while (row_len < n && y[row_len] == y[0])
+            row_len++;
+        if (int rc = install_sorted_view(ctx, centres, off.data(), T, levels, row_len < n ? row_len : 0))
+            return rc;
+    } else {
+        install_sorted_view(ctx, nullptr, nullptr, 0, levels, 0);    // every well a centre: sorted as it is
+    }
     ctx->has_targets = true;
     if (P_out)
         *P_out = P;
