@@ -534,3 +534,50 @@ def test_a_tiles_filter_error_comes_before_its_planes(sc, tmp_path):
     with pytest.raises(AssertionError):
         sc.load_bcl_gz_batch([str(junk), str(good)], d[:2], n, filters=[(str(okf), d[2]), (str(badf), d[3])])
     sc.free(buf)
+
+
+def test_failed_cycles_are_decoded_beside_the_batch_not_after_it(sc, tmp_path):
+    """A fifth of the planes are failed cycles (every well a no-call: the stream expands a
+    thousandfold, which the GPU decoder declines).  The reader thread that meets such a file decodes
+    it at once on the host, while the rest of the batch is still being read, copied and inflated - so
+    three batches in flight stay three batches in flight instead of each ending in a serial host tail.
+    Every plane right, every failed cycle counted as decoded early, both layouts."""
+    from concurrent.futures import ThreadPoolExecutor
+    n, per = 200003, 20
+    stride = (n + 255) // 256 * 256
+    buf = sc.malloc(3 * per * stride + 256)
+    sets, n_zero = [], 0
+    for t in range(3):
+        spec = synth.SynthSpec(seed=40 + t, n_clusters=n, row=400, qual_levels=7)
+        paths, dsts, want = [], [], []
+        for c in range(per):
+            payload = synth.plane_bytes(spec, 1, 1101 + t, c)
+            if c % 5 == 2:
+                payload = np.zeros(n, np.uint8)
+                n_zero += 1
+            p = tmp_path / ("s%d_c%d.bcl.gz" % (t, c))
+            p.write_bytes(_bcl(payload, 6))
+            paths.append(str(p))
+            dsts.append(buf + (t * per + c) * stride)
+            want.append(payload)
+        sets.append((paths, dsts, want))
+    e0, h0, g0 = (sc.get_option(o) for o in ("inflate_files_early", "inflate_files_host", "inflate_files_gpu"))
+    sc.memset(buf, 0xEE, 3 * per * stride)
+    with ThreadPoolExecutor(max_workers=3) as pool:
+        list(pool.map(lambda s: sc.load_bcl_gz_batch(s[0], s[1], n, threads=4), sets))
+    for paths, dsts, want in sets:
+        for d, w in zip(dsts, want):
+            assert (sc.d2h(d, n) == w).all()
+    assert sc.get_option("inflate_files_early") - e0 == n_zero == 12
+    assert sc.get_option("inflate_files_host") - h0 == n_zero             # nothing was left for a tail
+    assert sc.get_option("inflate_files_gpu") - g0 == 3 * per - n_zero
+    sc.free(buf)
+    # the interleaved layout: the host path scatters the plane into its byte lane itself
+    group = sc.malloc(4 * stride + 256)
+    sc.memset(group, 0xEE, 4 * stride)
+    paths, dsts, want = sets[0][0][:4], [group + q for q in range(4)], sets[0][2][:4]      # cycles 0..3, cycle 2 failed
+    sc.load_bcl_gz_batch(paths, dsts, n, threads=2, well_stride=4)
+    got = sc.d2h(group, 4 * n).reshape(n, 4)
+    for q in range(4):
+        assert (got[:, q] == want[q]).all(), q
+    sc.free(group)

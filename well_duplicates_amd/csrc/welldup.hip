@@ -296,6 +296,7 @@ struct wd_ctx {
     std::mutex inflate_mu;
     std::condition_variable inflate_cv;
     std::atomic<long long> inflate_files_gpu{0}, inflate_files_host{0};   // how the files of all batches were decoded
+    std::atomic<long long> inflate_files_early{0};     // ... of the host's: decoded by a reader thread while the batch was still being read
     std::atomic<long long> inflate_us_per_file{0};     // last batch: a file's time in the decode kernel, mean, microseconds
 };
 
@@ -1268,6 +1269,7 @@ try {
     else if (n == "dense_pack_blocks") *value = ctx->dense_pack_blocks;
     else if (n == "inflate_files_gpu") *value = ctx->inflate_files_gpu.load();
     else if (n == "inflate_files_host") *value = ctx->inflate_files_host.load();
+    else if (n == "inflate_files_early") *value = ctx->inflate_files_early.load();
     else if (n == "inflate_us_per_file") *value = ctx->inflate_us_per_file.load();
     else if (n == "well_stride") *value = ctx->well_stride;
     else if (n == "null_stream") *value = ctx->stream == nullptr ? 1 : 0;
@@ -2429,8 +2431,9 @@ static int load_tile_files_batch_impl(wd_ctx *ctx, int n_files, const char *cons
     constexpr int kChunks = wd_ctx::kInflateChunks, kStreams = wd_ctx::kInflateStreams;
     const size_t chunk_bytes = ctx->inflate_chunk_bytes;
 
-    enum : int { PENDING = 1, HOST = 2 };                                // beside the WD_* codes (<= 0)
-    std::vector<int> rc((size_t)n_files, PENDING);
+    enum : int { PENDING = 1, HOST = 2, EARLY = 3 };                     // beside the WD_* codes (<= 0)
+    std::vector<int> rc((size_t)n_files, PENDING), early_rc((size_t)n_files, WD_OK);
+    std::atomic<long long> n_early{0};
     std::vector<size_t> size((size_t)n_files, 0), offset((size_t)n_files, 0);   // offset: in the group's chunk
     std::vector<uint32_t> stream_off((size_t)n_files, 0);
     std::vector<uint64_t> trailer((size_t)n_files, 0);                   // CRC-32 | length << 32, as the file ends
@@ -2500,7 +2503,7 @@ static int load_tile_files_batch_impl(wd_ctx *ctx, int n_files, const char *cons
             }
             uint8_t *dst = ctx->inflate_chunks[g % kChunks].pinned + offset[(size_t)i];
             const size_t sz = size[(size_t)i];
-            bool ok = false;
+            bool ok = false, early = false;
             const int fd = open(paths[i], O_RDONLY);
             if (fd >= 0) {
                 size_t got = 0;
@@ -2522,10 +2525,23 @@ static int load_tile_files_batch_impl(wd_ctx *ctx, int n_files, const char *cons
                 rc[(size_t)i] = HOST;                                    // let the host path say what is wrong with it
             } else {
                 memcpy(&trailer[(size_t)i], dst + sz - 8, 8);
+                // A file that expands four hundredfold and more (a failed cycle: a plane of no-calls) holds
+                // stretches the GPU decoder declines (one piece of the stream, 256-fold).  Sending it
+                // through the launch only to decode it on the host afterwards would hold this batch back
+                // by a serial tail: this thread decodes it NOW, beside the reads, the copies and the launch.
+                if ((trailer[(size_t)i] >> 32) >= (uint64_t)sz * 400) {
+                    early = true;
+                    rc[(size_t)i] = EARLY;                               // (before the group is reported read: the chunk loop must not queue it)
+                }
             }
             if (groups[(size_t)g]->remaining.fetch_sub(1) == 1) {
                 std::lock_guard<std::mutex> lk(mu);
                 cv.notify_all();
+            }
+            if (early) {
+                const int hrc = wd_load_bcl_gz_strided(ctx, paths[i], dst_dev[i], n_clusters, well_stride);
+                early_rc[(size_t)i] = hrc;
+                n_early.fetch_add(1);
             }
         }
     };
@@ -2659,6 +2675,14 @@ static int load_tile_files_batch_impl(wd_ctx *ctx, int n_files, const char *cons
         cv.notify_all();
     }
     pool.join();
+    std::vector<uint8_t> was_early((size_t)n_files, 0);
+    for (int i = 0; i < n_files; i++)
+        if (rc[(size_t)i] == EARLY) {
+            rc[(size_t)i] = early_rc[(size_t)i];                         // the host loader's verdict, as for every file it takes
+            was_early[(size_t)i] = 1;
+        }
+    ctx->inflate_files_host += n_early.load();
+    ctx->inflate_files_early += n_early.load();
     if (getenv("WD_INFLATE_STATS"))
         fprintf(stderr, "[wd inflate] chunk loop %.1f ms for %d chunks: waited %.1f ms for the readers, %.1f ms for chunk copies\n",
                 1e3 * std::chrono::duration<double>(std::chrono::steady_clock::now() - loop_t0).count(), n_groups,
@@ -2724,7 +2748,7 @@ static int load_tile_files_batch_impl(wd_ctx *ctx, int n_files, const char *cons
     ctx->inflate_files_host += (long long)todo.size();
     long long by_gpu = 0;
     for (int i = 0; i < n_files; i++)
-        by_gpu += rc[(size_t)i] == WD_OK && !(is_filter && is_filter[i]);
+        by_gpu += rc[(size_t)i] == WD_OK && !(is_filter && is_filter[i]) && !was_early[(size_t)i];
     ctx->inflate_files_gpu += by_gpu;
     if (!todo.empty()) {
         std::atomic<size_t> next{0};
