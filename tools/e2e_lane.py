@@ -77,13 +77,30 @@ try:
               % (" ".join(extra), dt, r1.ru_utime - r0.ru_utime, r1.ru_stime - r0.ru_stime), flush=True)
         return dt, buf.getvalue()
     texts = set()
+    # WD_LANE_VARIANTS="name:ENV=val,ENV=val;name2:..." - the same lane under other environments
+    for variant in filter(None, os.environ.get("WD_LANE_VARIANTS", "").split(";")):
+        name, _, assigns = variant.partition(":")
+        saved = {}
+        for a in filter(None, assigns.split(",")):
+            key, _, val = a.partition("=")
+            saved[key] = os.environ.get(key)
+            os.environ[key] = val
+        run(["--tile-batch", str(batches[0])])
+        s, text = min(run(["--tile-batch", str(batches[0])]) for _ in range(3))
+        texts.add(text)
+        print("variant %-24s: %.3f s = %.2f ms per tile" % (name, s, s / n_tiles * 1e3), flush=True)
+        for key, val in saved.items():
+            if val is None:
+                os.environ.pop(key, None)
+            else:
+                os.environ[key] = val
     for tbatch in batches:
         run(["--tile-batch", str(tbatch)])
         s, text = min(run(["--tile-batch", str(tbatch)]) for _ in range(2))
         texts.add(text)
         print("gpu inflate, --tile-batch %2d: %.3f s = %.2f ms per tile, %.1f GB/s of plane bytes"
               % (tbatch, s, s / n_tiles * 1e3, n_tiles * cycles * n / s / 1e9), flush=True)
-    for tbatch in batches[-1:]:
+    for tbatch in ([] if os.environ.get("WD_LANE_NO_HOST") else batches[-1:]):
         s, text = min(run(["--tile-batch", str(tbatch), "--host-inflate"]) for _ in range(2))
         texts.add(text)
         print("host inflate, --tile-batch %2d: %.3f s = %.2f ms per tile" % (tbatch, s, s / n_tiles * 1e3), flush=True)

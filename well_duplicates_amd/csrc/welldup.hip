@@ -366,8 +366,8 @@ constexpr int kLevB2 = 8;
 // wd_last_kernel(), so that a counter profile can be tied to the kernel that really ran.
 #define WD_LAUNCH_Q(STR, B1_, LEVH_, WS_, LDS_)                                                          \
     do {                                                                                                 \
-        snprintf(ctx->last_kernel, sizeof(ctx->last_kernel), "k_scan_q<%s, %d, %d, %d>", (STR) ? "true" : "false", \
-                 (int)(B1_), (int)(LEVH_), (int)(WS_));                                                  \
+        snprintf(ctx->last_kernel, sizeof(ctx->last_kernel), "k_scan_q<%s, %d, %d, %d>%s", (STR) ? "true" : "false", \
+                 (int)(B1_), (int)(LEVH_), (int)(WS_), a.perm ? ", targets sorted by centre" : "");      \
         hipLaunchKernelGGL((k_scan_q<(STR), (B1_), (LEVH_), (WS_)>), grid, dim3(kBlock), (LDS_), ctx->stream, a); \
     } while (0)
 
@@ -2338,6 +2338,20 @@ struct InflateTurn {
     InflateTurn &operator=(const InflateTurn &) = delete;
 };
 
+// how the ring's chunks are pinned (WD_RING_FLAGS: experiments with what the readers' writes cost the DMA)
+unsigned ring_flags()
+{
+    const char *e = getenv("WD_RING_FLAGS");
+    if (!e)
+        return hipHostMallocDefault;
+    unsigned f = 0;
+    if (strstr(e, "wc")) f |= hipHostMallocWriteCombined;
+    if (strstr(e, "noncoherent")) f |= hipHostMallocNonCoherent;
+    if (strstr(e, "coherent") && !strstr(e, "noncoherent")) f |= hipHostMallocCoherent;
+    if (strstr(e, "portable")) f |= hipHostMallocPortable;
+    return f;
+}
+
 // buffers of a batch: pinned ring, streams, arena for `arena_bytes` of compressed files, n job slots
 int inflate_prepare(wd_ctx *ctx, wd_ctx::InflateSlot &sl, int n_chunks, size_t arena_bytes, size_t n_jobs)
 {
@@ -2358,7 +2372,7 @@ int inflate_prepare(wd_ctx *ctx, wd_ctx::InflateSlot &sl, int n_chunks, size_t a
         wd_ctx::InflateChunk &ch = ctx->inflate_chunks[c];
         if (!ch.copied && hipEventCreateWithFlags(&ch.copied, hipEventDisableTiming | hipEventBlockingSync) != hipSuccess)
             return WD_ERR_HIP;
-        if (!ch.pinned && hipHostMalloc((void **)&ch.pinned, ctx->inflate_chunk_cap + 64, hipHostMallocDefault) != hipSuccess)
+        if (!ch.pinned && hipHostMalloc((void **)&ch.pinned, ctx->inflate_chunk_cap + 64, ring_flags()) != hipSuccess)
             return WD_ERR_NOMEM;
     }
     for (auto &st : ctx->inflate_streams)
