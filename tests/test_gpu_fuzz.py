@@ -67,6 +67,7 @@ def test_fuzz(seed):
     tiles = [(1, 1101), (2, 1203), (3, 2101)]
     cycles = list(range(2, 2 + L))
     with Scanner(0) as sc:
+        sc.set_option("sort_strip", int(rng.choice([0, 8, 16, 30, 256])))
         sc.set_targets(centre, lvl_off, nbr)
         tb = TileBatch(sc, len(tiles), L, n)
         tb.fill_synthetic(spec, tiles, cycles)
@@ -84,7 +85,14 @@ def test_fuzz(seed):
                         "dense_kernel": int(rng.choice([-1, 0, 1])) if trial else -1,
                         "dense_pack": int(rng.choice([-1, 0, 1])) if trial else -1,
                         "early_exit": int(rng.integers(0, 2)) if trial == 2 else 1,
-                        "queue_first": int(rng.choice([0, 1, 2, 3, 4, 5, 6, 7, 8]))}
+                        "queue_first": int(rng.choice([0, 1, 2, 3, 4, 5, 6, 7, 8])),
+                        # round 3: the walk order of the queue kernels (the strips were laid out when the
+                        # targets were set, with the row length 61 read off the neighbour lists), the closed
+                        # form or the banded DP for Levenshtein <= 2, the dense scan in parts
+                        "sort_targets": int(rng.integers(0, 2)) if trial else 1,
+                        "lev2_closed": int(rng.integers(0, 2)) if trial else 1,
+                        "dense_overlap": int(rng.integers(0, 2)) if trial else 0,
+                        "dense_part_tiles": int(rng.choice([0, 1, 2]))}
                 for name, v in opts.items():
                     sc.set_option(name, v)
                 try:
@@ -186,7 +194,10 @@ def test_fuzz_window_groups(seed):
                             "dense_windows": int(rng.integers(0, 2)) if trial else 1,
                             "dense_tile_chunk": int(rng.choice([1, 2, 3, 8])),
                             "dense_queue_cap": int(rng.choice([0, 0, 1, 3, 64])),
-                            "dense_pack": int(rng.choice([-1, 0, 1])) if trial else -1}
+                            "dense_pack": int(rng.choice([-1, 0, 1])) if trial else -1,
+                            "dense_overlap": int(rng.integers(0, 2)) if trial else 0,
+                            "dense_part_tiles": int(rng.choice([0, 1, 2, 3])),
+                            "dense_pack_blocks": int(rng.choice([0, 7, 1024]))}
                     for name, v in opts.items():
                         sc.set_option(name, v)
                     blocks, pt = tb.count(mode, k, per_target=True)
