@@ -34,6 +34,8 @@
 #include <string.h>
 
 #include <fcntl.h>
+#include <emmintrin.h>
+#include <sched.h>
 #include <sys/stat.h>
 #include <unistd.h>
 
@@ -2338,6 +2340,101 @@ struct InflateTurn {
     InflateTurn &operator=(const InflateTurn &) = delete;
 };
 
+// Reader threads of a batch: what the caller asks for, but no more than the CPUs this process may use
+// (its affinity mask and its cgroup's quota).  The readers copy at memory speed; more of them than
+// CPUs only makes the quota run out in the middle of a period, and every thread of the process stops
+// until the next one (tools/ring_probe.hip: 54 GB/s with 16 threads on 16 CPUs, 21 with 32).
+inline int reader_threads(int asked)
+{
+    static const int cpus = [] {
+        int n = (int)std::thread::hardware_concurrency();
+        cpu_set_t set;
+        if (sched_getaffinity(0, sizeof(set), &set) == 0)
+            n = std::min(n > 0 ? n : 1 << 20, CPU_COUNT(&set));
+        if (FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r")) {         // "max 100000" or "<quota> <period>"
+            long long quota = 0, period = 0;
+            if (fscanf(f, "%lld %lld", &quota, &period) == 2 && quota > 0 && period > 0)
+                n = std::min<long long>(n, std::max<long long>(1, quota / period));
+            fclose(f);
+        }
+        return std::max(1, n);
+    }();
+    if (const char *e = getenv("WD_READER_THREADS"))
+        return std::max(1, std::min(atoi(e), 256));
+    return std::max(1, std::min({asked, 256, cpus}));
+}
+
+// A file (or a stretch of one) from the page cache into a chunk of the pinned ring.
+//
+// pread() straight into the ring - what rounds 1 and 2 did - is a kernel copy with ordinary stores: the
+// chunk's lines sit dirty in the caches of whichever cores ran the readers, and the DMA engine that
+// reads the chunk a moment later has to pull them out of there: 34-40 GB/s through the ring instead of
+// the 54 GB/s the engine does on memory nobody has just written (tools/ring_probe.hip: the same ring
+// filled by memcpy 49, by non-temporal stores 54, by pread 40.5 with 16 threads and 34 with 32).  So the
+// readers pread into a small buffer of their own (it stays in the core's L2) and move it on with
+// NON-TEMPORAL stores, which go to memory past the caches: the engine finds the chunk in DRAM.
+// dst is 16-byte aligned (the files of a chunk start at multiples of 16).
+constexpr size_t kBounceBytes = 256u << 10;
+
+inline void nt_copy(uint8_t *dst, const uint8_t *src, size_t n)
+{
+    size_t i = 0;
+    if (((uintptr_t)dst & 15) == 0) {
+        for (; i + 64 <= n; i += 64) {
+            const __m128i a = _mm_loadu_si128((const __m128i *)(src + i)), b = _mm_loadu_si128((const __m128i *)(src + i + 16));
+            const __m128i c = _mm_loadu_si128((const __m128i *)(src + i + 32)), d = _mm_loadu_si128((const __m128i *)(src + i + 48));
+            _mm_stream_si128((__m128i *)(dst + i), a);
+            _mm_stream_si128((__m128i *)(dst + i + 16), b);
+            _mm_stream_si128((__m128i *)(dst + i + 32), c);
+            _mm_stream_si128((__m128i *)(dst + i + 48), d);
+        }
+    }
+    if (i < n)
+        memcpy(dst + i, src + i, n - i);
+}
+
+// -> bytes read (== n on success).  `direct`: the old way (WD_RING_DIRECT=1, for comparisons).
+inline size_t read_into_ring(int fd, uint8_t *dst, size_t n, off_t at, std::vector<uint8_t> &bounce, bool direct)
+{
+    size_t got = 0;
+    if (direct) {
+        while (got < n) {
+            const ssize_t k = pread(fd, dst + got, n - got, at + (off_t)got);
+            if (k <= 0)
+                break;
+            got += (size_t)k;
+        }
+        return got;
+    }
+    if (bounce.size() < kBounceBytes)
+        bounce.resize(kBounceBytes);
+    while (got < n) {
+        const ssize_t k = pread(fd, bounce.data(), std::min(kBounceBytes, n - got), at + (off_t)got);
+        if (k <= 0)
+            break;
+        nt_copy(dst + got, bounce.data(), (size_t)k);      // (got stays a multiple of 16 until the last piece)
+        got += (size_t)k;
+    }
+    _mm_sfence();                                           // the stores are on their way before the chunk is reported read
+    return got;
+}
+
+// Wait for a chunk's copy.  The events are blocking ones (a thread woken by an interrupt); WD_CHUNK_SPIN=1
+// polls instead, for experiments with what the wake-up costs.
+hipError_t wait_copied(hipEvent_t ev)
+{
+    static const bool spin = getenv("WD_CHUNK_SPIN") && atoi(getenv("WD_CHUNK_SPIN")) != 0;
+    if (!spin)
+        return hipEventSynchronize(ev);
+    for (;;) {
+        const hipError_t e = hipEventQuery(ev);
+        if (e != hipErrorNotReady)
+            return e;
+        for (int i = 0; i < 64; i++)
+            __builtin_ia32_pause();
+    }
+}
+
 // how the ring's chunks are pinned (WD_RING_FLAGS: experiments with what the readers' writes cost the DMA)
 unsigned ring_flags()
 {
@@ -2441,7 +2538,8 @@ static int load_tile_files_batch_impl(wd_ctx *ctx, int n_files, const char *cons
     InflateTurn batch_lock(ctx);
     wd_ctx::InflateSlot &slot = ctx->inflate_slots[batch_lock.ticket % wd_ctx::kInflateSlots];
     std::lock_guard<std::mutex> slot_lock(slot.mu);
-    threads = std::max(1, std::min(threads, 256));
+    threads = reader_threads(threads);
+    const bool ring_direct = getenv("WD_RING_DIRECT") && atoi(getenv("WD_RING_DIRECT")) != 0;
     constexpr int kChunks = wd_ctx::kInflateChunks, kStreams = wd_ctx::kInflateStreams;
     const size_t chunk_bytes = ctx->inflate_chunk_bytes;
 
@@ -2520,14 +2618,8 @@ static int load_tile_files_batch_impl(wd_ctx *ctx, int n_files, const char *cons
             bool ok = false, early = false;
             const int fd = open(paths[i], O_RDONLY);
             if (fd >= 0) {
-                size_t got = 0;
-                while (got < sz) {
-                    const ssize_t k = pread(fd, dst + got, sz - got, (off_t)got);
-                    if (k <= 0)
-                        break;
-                    got += (size_t)k;
-                }
-                ok = got == sz;
+                thread_local std::vector<uint8_t> bounce;
+                ok = read_into_ring(fd, dst, sz, 0, bounce, ring_direct) == sz;
                 close(fd);
             }
             if (ok && is_filter && is_filter[i]) {                       // .filter: header 0, 3, n (:148-152, :236), then the bytes
@@ -2574,9 +2666,13 @@ static int load_tile_files_batch_impl(wd_ctx *ctx, int n_files, const char *cons
     job_file.reserve(n_jobs);
     int hip_rc = WD_OK;
     hipStream_t copy_stream = ctx->inflate_streams[kStreams];
+    const int copy_depth = std::max(1, std::min(kChunks - 1, getenv("WD_COPY_DEPTH") ? atoi(getenv("WD_COPY_DEPTH")) : 1));
     const int si = (int)(batch_lock.ticket % kStreams);                  // consecutive batches decode on alternate streams
     size_t j0 = 0;                                                       // first job of the launch being gathered
     double wait_read_s = 0, wait_copy_s = 0;                             // (WD_INFLATE_STATS) what the chunk loop waits for
+    const bool dma_probe = getenv("WD_INFLATE_STATS") && atoi(getenv("WD_INFLATE_STATS")) >= 2;
+    std::vector<hipEvent_t> dma_ev;
+    size_t dma_bytes = 0;
     const auto loop_t0 = std::chrono::steady_clock::now();
     for (int g = 0; g < n_groups && hip_rc == WD_OK; g++) {
         Group &grp = *groups[(size_t)g];
@@ -2607,11 +2703,21 @@ static int load_tile_files_batch_impl(wd_ctx *ctx, int n_files, const char *cons
             j.pad_ = 0;
             job_file.push_back(i);
         }
+        if (dma_probe && (int)dma_ev.size() < 2 * n_groups) {           // (WD_INFLATE_STATS=2: how long the engine itself takes)
+            hipEvent_t e0 = nullptr, e1 = nullptr;
+            (void)hipEventCreate(&e0);
+            (void)hipEventCreate(&e1);
+            dma_ev.push_back(e0);
+            dma_ev.push_back(e1);
+            (void)hipEventRecord(e0, copy_stream);
+        }
         if (hipMemcpyAsync(dev, ch.pinned, grp.bytes, hipMemcpyHostToDevice, copy_stream) != hipSuccess ||
+            (dma_probe && hipEventRecord(dma_ev.back(), copy_stream) != hipSuccess) ||
             hipEventRecord(ch.copied, copy_stream) != hipSuccess) {
             hip_rc = WD_ERR_HIP;
             break;
         }
+        dma_bytes += grp.bytes;
         for (int i : plain) {
             if (n_clusters > 0 && hipMemcpyAsync(dst_dev[i], dev + offset[(size_t)i] + 12, (size_t)n_clusters,
                                                   hipMemcpyDeviceToDevice, copy_stream) != hipSuccess) {
@@ -2669,17 +2775,19 @@ static int load_tile_files_batch_impl(wd_ctx *ctx, int n_files, const char *cons
             }
             j0 = job_file.size();
         }
-        if (g >= 1) {
-            // group g - 1 + kChunks wants the chunk of group g - 1: once that copy (asked for a turn
-            // ago) is done, the readers may fill every chunk but the one just sent off
+        if (g >= copy_depth) {
+            // group g - copy_depth + kChunks wants the chunk of group g - copy_depth: once that copy is
+            // done the readers may fill it again.  copy_depth copies are queued at any time, so that the
+            // engine has the next one at hand when this thread is late in noticing that one has ended
+            // (it shares its CPUs with the readers)
             const auto w0 = std::chrono::steady_clock::now();
-            if (hipEventSynchronize(ctx->inflate_chunks[(g - 1) % kChunks].copied) != hipSuccess) {
+            if (wait_copied(ctx->inflate_chunks[(g - copy_depth) % kChunks].copied) != hipSuccess) {
                 hip_rc = WD_ERR_HIP;
                 break;
             }
             wait_copy_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - w0).count();
             std::lock_guard<std::mutex> lk(mu);
-            free_upto = g + kChunks;
+            free_upto = g - copy_depth + 1 + kChunks;
             cv.notify_all();
         }
     }
@@ -2701,6 +2809,24 @@ static int load_tile_files_batch_impl(wd_ctx *ctx, int n_files, const char *cons
         fprintf(stderr, "[wd inflate] chunk loop %.1f ms for %d chunks: waited %.1f ms for the readers, %.1f ms for chunk copies\n",
                 1e3 * std::chrono::duration<double>(std::chrono::steady_clock::now() - loop_t0).count(), n_groups,
                 1e3 * wait_read_s, 1e3 * wait_copy_s);
+    if (dma_probe && !dma_ev.empty()) {
+        (void)hipStreamSynchronize(copy_stream);
+        double busy = 0, span = 0, longest = 0;
+        for (size_t q = 0; q + 1 < dma_ev.size(); q += 2) {
+            float ms = 0;
+            (void)hipEventElapsedTime(&ms, dma_ev[q], dma_ev[q + 1]);
+            busy += ms;
+            longest = std::max<double>(longest, ms);
+        }
+        float ms = 0;
+        (void)hipEventElapsedTime(&ms, dma_ev.front(), dma_ev.back());
+        span = ms;
+        fprintf(stderr, "[wd inflate] the copies themselves: %.1f MB in %zu copies, engine busy %.1f ms (%.1f GB/s while copying, "
+                        "longest copy %.2f ms), first start to last end %.1f ms\n",
+                dma_bytes / 1e6, dma_ev.size() / 2, busy, dma_bytes / 1e6 / std::max(busy, 1e-9), longest, span);
+        for (hipEvent_t e : dma_ev)
+            (void)hipEventDestroy(e);
+    }
     // the next batch may start reading; this one waits for its last results
     // (.filter copies ride on the copy stream: the decode stream's event must come after them)
     if (hip_rc == WD_OK && n_groups &&
@@ -2961,7 +3087,8 @@ static int load_cbcl_batch_impl(wd_ctx *ctx, int n, const char *const *paths, co
     InflateTurn batch_lock(ctx);
     wd_ctx::InflateSlot &slot = ctx->inflate_slots[batch_lock.ticket % wd_ctx::kInflateSlots];
     std::lock_guard<std::mutex> slot_lock(slot.mu);
-    threads = std::max(1, std::min(threads, 256));
+    threads = reader_threads(threads);
+    const bool ring_direct = getenv("WD_RING_DIRECT") && atoi(getenv("WD_RING_DIRECT")) != 0;
     constexpr int kChunks = wd_ctx::kInflateChunks, kStreams = wd_ctx::kInflateStreams;
     const size_t chunk_bytes = ctx->inflate_chunk_bytes;
     enum : int { PENDING = 1, HOST = 2 };
@@ -3113,14 +3240,8 @@ static int load_cbcl_batch_impl(wd_ctx *ctx, int n, const char *const *paths, co
             bool ok = false;
             const int fd = open(paths[i], O_RDONLY);
             if (fd >= 0) {
-                size_t got = 0;
-                while (got < e.csize) {
-                    const ssize_t k = pread(fd, dst + got, e.csize - got, (off_t)(e.pos + got));
-                    if (k <= 0)
-                        break;
-                    got += (size_t)k;
-                }
-                ok = got == e.csize;
+                thread_local std::vector<uint8_t> bounce;
+                ok = read_into_ring(fd, dst, e.csize, (off_t)e.pos, bounce, ring_direct) == e.csize;
                 close(fd);
             }
             if (!ok || !inf_gzip_header(dst, e.csize, &e.stream_off))
