@@ -217,3 +217,17 @@ def test_malformed_tokens_raise_what_the_reference_raises(tmp_path):
         else:
             with pytest.raises(ValueError):
                 load_targets(f, levels=3)
+
+
+def test_vectorised_regularity_check_equals_the_regular_expression():
+    """_regular() decides what the bulk parser may touch; it must accept exactly the texts the
+    regular expression it replaces accepts (decimal integers, each followed by one comma or newline)."""
+    import random
+    from well_duplicates_amd import targets
+    random.seed(3)
+    alphabet = "0123456789,,\n\n--x +"
+    for _ in range(60000):
+        t = "".join(random.choice(alphabet) for _ in range(random.randint(0, 12)))
+        assert bool(targets._REGULAR.fullmatch(t)) == targets._regular(t), repr(t)
+    for t in ("", "5", "5\n", "-5\n1,-2\n", "5\n1,2,", "5,\n", "\n5", "5\n\n", "1,é\n", "5\n1,2\n3,4"):
+        assert bool(targets._REGULAR.fullmatch(t)) == targets._regular(t), repr(t)

@@ -46,25 +46,41 @@ class BCLReader:
         basecalls = os.listdir(os.path.join(location, "Data", "Intensities", "BaseCalls"))
         self.lanes = [d for d in basecalls if re.match(r"L\d\d\d$", d)]
         self.location = location
+        self._listings = {}            # lane directory -> (names, number of cycle directories), listed once
 
     def get_tile(self, lane, tile):
         lane_dir = str(lane)
         if lane_dir not in self.lanes:
             lane_dir = "L%03d" % int(lane_dir)
         data_dir = os.path.join(self.location, "Data", "Intensities", "BaseCalls", lane_dir)
-        return Tile(data_dir, tile)
+        # (the reference lists the directory for every tile, :124, :141; a lane has hundreds of tiles)
+        def listed():
+            names = os.listdir(data_dir)
+            return names, len([f for f in names if re.match(r"C\d+.1$", f)])
+        if data_dir not in self._listings:
+            self._listings[data_dir] = listed()
+        try:
+            return Tile(data_dir, tile, self._listings[data_dir])
+        except RuntimeError:                     # not in the listing: the directory may have grown since
+            self._listings[data_dir] = listed()
+            return Tile(data_dir, tile, self._listings[data_dir])
 
 
 class Tile:
     """One tile's files (bcl_direct_reader.py:108-156)."""
 
-    def __init__(self, data_dir, tile):
+    def __init__(self, data_dir, tile, listing=None):
         self.data_dir = data_dir
         self.tile = tile
         self.bcl_filename = None
-        listing = os.listdir(data_dir)
+        if listing is None:
+            names = os.listdir(data_dir)
+            listing = (names, len([f for f in names if re.match(r"C\d+.1$", f)]))
+        listing, n_cycle_dirs = listing
+        key = "_%s" % tile
         for name in listing:
-            m = re.match("(.+_%s).filter" % tile, name)
+            # the reference's pattern (:124-129), tried only on names that can match it
+            m = re.match("(.+_%s).filter" % tile, name) if key in name else None
             if m:
                 self.bcl_filename = m.group(1) + ".bcl.gz"
                 self.filter_file = os.path.join(data_dir, name)
@@ -73,7 +89,7 @@ class Tile:
             raise RuntimeError("Cannot find a .filter file for tile %s" % tile)
         # "L00<lane>_<surface>.cbcl", surface = first digit of the tile id (:137)
         self.cbcl_filename = "%s_%s.cbcl" % (os.path.basename(data_dir), str(tile)[0])
-        self.num_cycles = len([f for f in listing if re.match(r"C\d+.1$", f)])
+        self.num_cycles = n_cycle_dirs
         with open(self.filter_file, "rb") as fh:
             head = struct.unpack("<III", fh.read(12))
         assert tuple(head[0:2]) == (0, 3)

@@ -180,9 +180,18 @@ def scan_lane(sc: Scanner, reader, lane, tiles, cycle_list, mode, k, csr, wells,
     levels = lvl_off.shape[1] - 1
     counts, logs = {}, {}
     if tile_batch <= 0:
-        # about 512 files per batch - what one launch of the GPU decoder holds at once - in batches of
-        # equal size (a short last batch would cost a full round of the decoder)
-        per = max(1, 512 // max(1, len(cycle_list)))
+        # as many files per batch as one launch of the GPU decoder holds at once - 512, or 768 of files
+        # that expand less than 1.75-fold (its small-window form; base calls with binned qualities do:
+        # the first file's size tells) - in batches of equal size (a short last batch would cost a full
+        # round of the decoder all the same)
+        room = 512
+        try:
+            first = reader.get_tile(lane, tiles[0])
+            if os.path.getsize(first.plane_path(cycle_list[0])) * 7 >= (first.num_clusters + 4) * 4:
+                room = 700
+        except (OSError, IndexError, RuntimeError, AssertionError):
+            pass                                # (whatever is wrong with the first tile is reported when it is loaded)
+        per = max(1, room // max(1, len(cycle_list) + 1))
         n_batches = max(1, -(-len(tiles) // per))
         tile_batch = max(1, -(-len(tiles) // n_batches))
     batches = [tiles[b0:b0 + tile_batch] for b0 in range(0, len(tiles), tile_batch)]

@@ -21,6 +21,31 @@ import numpy as np
 _REGULAR = re.compile(r"(?:-?[0-9]+[,\n])*(?:-?[0-9]+)?")
 
 
+def _regular(text: str) -> bool:
+    """`_REGULAR.fullmatch(text)` - decimal integers, each followed by one comma or newline (the last
+    one may go without) - in a few numpy passes over the bytes: the regular expression costs 20-50 ms
+    on the 1.7 MB of a 2500-target file, a tenth of a lane's run."""
+    try:
+        b = np.frombuffer(text.encode("ascii"), dtype=np.uint8)
+    except UnicodeEncodeError:
+        return False
+    if b.size == 0:
+        return True
+    digit = (b >= 48) & (b <= 57)
+    sep = (b == 44) | (b == 10)
+    minus = b == 45
+    if not (digit | sep | minus).all():
+        return False
+    if sep[0] or minus[-1]:
+        return False
+    # a separator follows a digit; a minus follows a separator (or opens the text) and precedes a digit
+    if (sep[1:] & ~digit[:-1]).any():
+        return False
+    if (minus[1:] & ~sep[:-1]).any() or (minus[:-1] & ~digit[1:]).any():
+        return False
+    return True
+
+
 class Target:
     """One centre well plus its per-level neighbour wells: [[c], [lvl 1 ...], [lvl 2 ...]]."""
 
@@ -172,22 +197,26 @@ def load_targets_csr(filename, level, limit=None):
     then takes load_targets(), which raises what the reference raises (target.py:6-40, :72-78)."""
     with open(filename, "r") as fh:
         text = fh.read()
-    if not text or not _REGULAR.fullmatch(text):
+    if not text or not _regular(text):
         # anything but decimal integers separated by single commas / newlines ('-' alone, '0x10',
         # '7abc', blanks, '+5', '1_0' ...): numpy's bulk parser would read some of those as numbers
         # where int() raises (target.py:31) - the reference's parser decides
         return None
-    lines = text.split("\n")
-    if lines[-1] == "":
-        lines.pop()                         # the last line's own newline
-    if not lines or "" in lines:
-        return None
-    commas = np.fromiter((ln.count(",") for ln in lines), dtype=np.int64, count=len(lines))
+    # commas per line, from the bytes (a regular text has no empty line: every newline follows a digit)
+    b = np.frombuffer(text.encode("ascii"), dtype=np.uint8)
+    ends = np.flatnonzero(b == 10)
+    if b[-1] == 44:
+        return None                         # the text ends in a comma: an empty last token
+    if b[-1] != 10:
+        ends = np.append(ends, b.size)      # the last line has no newline of its own
+    comma_before = np.concatenate([[0], np.cumsum(b == 44)])
+    commas = np.diff(np.concatenate([[0], comma_before[ends]])).astype(np.int64)
+    n_lines = int(ends.size)
     starts = np.flatnonzero(commas == 0)    # a line without a comma starts a record (target.py:27)
     if starts.size == 0 or starts[0] != 0:
         return None
-    per = int(starts[1]) if starts.size > 1 else len(lines)
-    if per < level + 1 or len(lines) % per or not np.array_equal(starts, np.arange(0, len(lines), per)):
+    per = int(starts[1]) if starts.size > 1 else n_lines
+    if per < level + 1 or n_lines % per or not np.array_equal(starts, np.arange(0, n_lines, per)):
         return None
     import warnings
     try:
@@ -196,11 +225,11 @@ def load_targets_csr(filename, level, limit=None):
             flat = np.fromstring(text.replace("\n", ","), dtype=np.int64, sep=",")
     except ValueError:
         return None
-    if flat.size != int(commas.sum()) + len(lines):
+    if flat.size != int(commas.sum()) + n_lines:
         return None                         # something that is not an integer stopped the parse
     if flat.size and (flat.min() < -(2 ** 31) or flat.max() >= 2 ** 31):
         return None
-    n_rec = len(lines) // per
+    n_rec = n_lines // per
     T = min(n_rec, int(limit)) if limit else n_rec
     line_len = (commas + 1).reshape(n_rec, per)[:T]
     line_off = np.concatenate([[0], np.cumsum(commas + 1)])[:-1].reshape(n_rec, per)[:T]
