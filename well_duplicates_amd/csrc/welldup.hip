@@ -193,6 +193,8 @@ struct wd_ctx {
     int win_kpad = 0;                 // row length of d_uoff / d_wdelta
     int win_dwords = 0;               // largest window of any group, in dwords
     long long n_uniform_groups = -1, n_window_groups = -1;   // -1: tables not built yet
+    int32_t *d_pblocks = nullptr;              // dense path: target blocks with a group for the gather kernel (window groups in use)
+    int n_pblocks = 0;
     uint32_t *d_tblflags = nullptr;   // scratch of the table builders: [0] offsets need 32 bits, [1] largest window
     long long *d_gbase = nullptr;
     bool has_targets = false;
@@ -630,6 +632,25 @@ int ensure_dense_tables(wd_ctx *ctx)
             ctx->n_uniform_groups += guni[g] != 0;
             ctx->n_window_groups += ginfo[g] != 0;
         }
+        // the target blocks (kWaves groups each) that hold a group the window kernel leaves to the gather
+        // kernel: k_dense_pairs is launched over this list, not over every block of the tile (with every
+        // well a centre that is ONE block - the last, partial group - and the launch over all 16 834 cost
+        // 29 us per 8 tiles to find it)
+        std::vector<int32_t> pb;
+        for (int b = 0; b * kWaves < groups; b++) {
+            bool any = false;
+            for (int w = 0; w < kWaves && b * kWaves + w < groups; w++)
+                any = any || ginfo[(size_t)(b * kWaves + w)] == 0;
+            if (any)
+                pb.push_back(b);
+        }
+        (void)hipFree(ctx->d_pblocks);
+        ctx->d_pblocks = nullptr;
+        ctx->n_pblocks = (int)pb.size();
+        if (!pb.empty()) {
+            WD_HIP(ctx, hipMalloc((void **)&ctx->d_pblocks, pb.size() * sizeof(int32_t)));
+            WD_HIP(ctx, hipMemcpy(ctx->d_pblocks, pb.data(), pb.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+        }
     }
     return WD_OK;
 }
@@ -875,6 +896,10 @@ int launch_dense(wd_ctx *ctx, const ScanArgs &a, int n_tiles, int64_t N, bool st
         const dim3 grid((unsigned)((long long)kXcds * ((dense_bpt + kXcds - 1) / kXcds) * ((nt + tc - 1) / tc)));
         const dim3 grid4((unsigned)((N + 4ll * kBlock - 1) / (4ll * kBlock)), (unsigned)nt);
         const dim3 grid1((unsigned)((N + kBlock - 1) / kBlock), (unsigned)nt);
+        // the gather kernel: over the listed target blocks only, when the window kernel takes the rest
+        d.pblocks = d.ginfo ? ctx->d_pblocks : nullptr;
+        d.n_pblocks = d.ginfo ? ctx->n_pblocks : 0;
+        const dim3 pgrid = d.n_pblocks > 0 ? dim3((unsigned)((long long)d.n_pblocks * ((nt + tc - 1) / tc))) : grid;
         if (aligned4 && strided)
             hipLaunchKernelGGL((k_dense_sig<true, true>), grid4, dim3(kBlock), 0, st, d);
         else if (aligned4)
@@ -893,9 +918,9 @@ int launch_dense(wd_ctx *ctx, const ScanArgs &a, int n_tiles, int64_t N, bool st
             hipLaunchKernelGGL((k_dense_pairs_win<MODE>), grid, dim3(kBlock), q_lds, st, d);                    \
         if (ctx->n_window_groups < n_groups || !d.ginfo) {                                                      \
             if (ctx->nbr_t16)                                                                                   \
-                hipLaunchKernelGGL((k_dense_pairs<MODE, true>), grid, dim3(kBlock), q_lds, st, d);             \
+                hipLaunchKernelGGL((k_dense_pairs<MODE, true>), pgrid, dim3(kBlock), q_lds, st, d);            \
             else                                                                                                \
-                hipLaunchKernelGGL((k_dense_pairs<MODE, false>), grid, dim3(kBlock), q_lds, st, d);           \
+                hipLaunchKernelGGL((k_dense_pairs<MODE, false>), pgrid, dim3(kBlock), q_lds, st, d);          \
         }                                                                                                       \
     } while (0)
         if (pmode == 0)
@@ -1078,6 +1103,7 @@ void wd_destroy(wd_ctx *ctx)
     (void)hipFree(ctx->d_queue);
     (void)hipFree(ctx->d_qcnt);
     (void)hipFree(ctx->d_cand);
+    (void)hipFree(ctx->d_pblocks);
     (void)hipFree(ctx->d_centre_q);
     (void)hipFree(ctx->d_lvl_off_q);
     (void)hipFree(ctx->d_perm);
