@@ -2,7 +2,8 @@
 """A whole lane end to end: 96 full-size HiSeq X tiles x 50 cycles (4 800 .bcl.gz files, gzip -6,
 binned qualities, written on the fly from GPU-generated planes), then the CLI with the reference's
 default metric for several --tile-batch values, with the GPU decoder and with --host-inflate.
-Usage: e2e_lane.py [tiles=96] [tile-batch,tile-batch,...] [reader threads]"""
+Usage: e2e_lane.py [tiles=96] [tile-batch,tile-batch,...] [reader threads] [lanes=1]
+(further lanes are hard links of lane 1's files under their own names: the same bytes, read again)"""
 import gzip
 import io
 import os
@@ -22,6 +23,7 @@ n_tiles = int(sys.argv[1]) if len(sys.argv) > 1 else 96
 batches = [int(b) for b in sys.argv[2].split(",")] if len(sys.argv) > 2 else [8, 16, 32]
 cycles = 50
 threads = int(sys.argv[3]) if len(sys.argv) > 3 else min(32, os.cpu_count() or 1)
+n_lanes = int(sys.argv[4]) if len(sys.argv) > 4 else 1
 rows, cols = workload.HISEQ4000_ROWS, workload.HISEQ4000_COLS
 n = rows * cols
 centre, lvl_off, nbr = workload.honeycomb_targets(rows, cols, 2500, 5, seed=13)
@@ -53,6 +55,15 @@ try:
                     fh.write(synth.filter_file_bytes(tb.download_filter(i)))
             tb.free()
             print("written %d tiles, %.0f s" % (first + len(part), time.perf_counter() - t0), flush=True)
+    for lane in range(2, n_lanes + 1):
+        ldir2 = os.path.join(root, "Data", "Intensities", "BaseCalls", "L%03d" % lane)
+        for c in range(cycles):
+            os.makedirs(os.path.join(ldir2, "C%d.1" % (c + 1)))
+            for t in tiles:
+                os.link(os.path.join(ldir, "C%d.1" % (c + 1), "s_1_%s.bcl.gz" % t),
+                        os.path.join(ldir2, "C%d.1" % (c + 1), "s_%d_%s.bcl.gz" % (lane, t)))
+        for t in tiles:
+            os.link(os.path.join(ldir, "s_1_%s.filter" % t), os.path.join(ldir2, "s_%d_%s.filter" % (lane, t)))
     tfile = os.path.join(root, "targets.list")
     with open(tfile, "w") as fh:
         for t in range(centre.shape[0]):
@@ -61,7 +72,8 @@ try:
                 fh.write(",".join(str(int(w)) for w in nbr[lvl_off[t, l]:lvl_off[t, l + 1]]) + "\n")
     print("%d files, %.2f GB compressed, %.2f GB of planes, %d reader threads, %d cpus"
           % (n_tiles * cycles, gz[0] / 1e9, n_tiles * cycles * n / 1e9, threads, os.cpu_count()), flush=True)
-    argv = ["-f", tfile, "-n", "2500", "-l", "5", "-s", "hiseq_x", "-r", root, "-i", "1", "-t", ",".join(tiles),
+    argv = ["-f", tfile, "-n", "2500", "-l", "5", "-s", "hiseq_x", "-r", root,
+            "-i", ",".join(str(ln) for ln in range(1, n_lanes + 1)), "-t", ",".join(tiles),
             "--cycles", "0-%d" % cycles, "-q", "-S", "--threads", str(threads)]
 
     def run(extra):
@@ -98,8 +110,8 @@ try:
         run(["--tile-batch", str(tbatch)])
         s, text = min(run(["--tile-batch", str(tbatch)]) for _ in range(2))
         texts.add(text)
-        print("gpu inflate, --tile-batch %2d: %.3f s = %.2f ms per tile, %.1f GB/s of plane bytes"
-              % (tbatch, s, s / n_tiles * 1e3, n_tiles * cycles * n / s / 1e9), flush=True)
+        print("gpu inflate, --tile-batch %2d: %.3f s for %d lane(s) = %.2f ms per tile, %.1f GB/s of plane bytes"
+              % (tbatch, s, n_lanes, s / (n_tiles * n_lanes) * 1e3, n_lanes * n_tiles * cycles * n / s / 1e9), flush=True)
     for tbatch in ([] if os.environ.get("WD_LANE_NO_HOST") else batches[-1:]):
         s, text = min(run(["--tile-batch", str(tbatch), "--host-inflate"]) for _ in range(2))
         texts.add(text)

@@ -166,41 +166,52 @@ class _Loading:
             f.result()                      # re-raises the loader's exception (FileNotFoundError, ...)
 
 
-def scan_lane(sc: Scanner, reader, lane, tiles, cycle_list, mode, k, csr, wells, tile_batch,
-              threads, want_log, overlap=True, interleave=1, gpu_inflate=True):
-    """The given tiles of one lane -> ({tile: TileCounts}, {tile: [log lines]}).
+def scan_lanes(sc: Scanner, reader, lane_tiles, cycle_list, mode, k, csr, wells, tile_batch,
+               threads, want_log, overlap=True, interleave=1, gpu_inflate=True, lane_done=None, into=None):
+    """lane_tiles: [(lane, [tiles])] in the order they are reported -> ({(lane, tile): TileCounts},
+    {(lane, tile): [log lines]}); `lane_done(lane)` is called when a lane's last tile has been scanned.
 
     Pipelined: while the GPU scans batch n (and its report rows and log lines are put together),
     batch n + 1 is being inflated and batch n + 2 read and copied, each into a TileBatch of its own
-    (the ctypes calls release the GIL).  Whatever goes wrong, every loader thread has
+    (the ctypes calls release the GIL).  A batch holds tiles of one lane, but the pipeline runs on from
+    one lane into the next: the first batches of lane n + 1 are on their way while the last ones of lane
+    n are decoded and scanned (a lane at a time, every lane paid for the fill and the drain of its own
+    pipeline: a tenth of a second of a 0.43 s lane).  Whatever goes wrong, every loader thread has
     finished before a TileBatch is freed or the exception leaves this function: the threads
     write through the scanner's copy streams into the batches' planes.
     """
     centre, lvl_off, nbr = csr
     levels = lvl_off.shape[1] - 1
-    counts, logs = {}, {}
-    if tile_batch <= 0:
-        # as many files per batch as one launch of the GPU decoder holds at once - 512, or 768 of files
-        # that expand less than 1.75-fold (its small-window form; base calls with binned qualities do:
-        # the first file's size tells) - in batches of equal size (a short last batch would cost a full
-        # round of the decoder all the same)
-        room = 512
-        try:
-            first = reader.get_tile(lane, tiles[0])
-            if os.path.getsize(first.plane_path(cycle_list[0])) * 7 >= (first.num_clusters + 4) * 4:
-                room = 700
-        except (OSError, IndexError, RuntimeError, AssertionError):
-            pass                                # (whatever is wrong with the first tile is reported when it is loaded)
-        per = max(1, room // max(1, len(cycle_list) + 1))
-        n_batches = max(1, -(-len(tiles) // per))
-        tile_batch = max(1, -(-len(tiles) // n_batches))
-    batches = [tiles[b0:b0 + tile_batch] for b0 in range(0, len(tiles), tile_batch)]
+    counts, logs = (into["counts"], into["logs"]) if into else ({}, {})
+    batches = []                            # (lane, [tiles]), never across a lane's end: an error stays its lane's
+    for lane, tiles in lane_tiles:
+        if not tiles:
+            continue
+        tb_n = tile_batch
+        if tb_n <= 0:
+            # as many files per batch as one launch of the GPU decoder holds at once - 512, or 768 of files
+            # that expand less than 1.75-fold (its small-window form; base calls with binned qualities do:
+            # the first file's size tells) - in batches of equal size (a short last batch would cost a full
+            # round of the decoder all the same)
+            room = 512
+            try:
+                first = reader.get_tile(lane, tiles[0])
+                if os.path.getsize(first.plane_path(cycle_list[0])) * 7 >= (first.num_clusters + 4) * 4:
+                    room = 700
+            except (OSError, IndexError, RuntimeError, AssertionError):
+                pass                            # (whatever is wrong with the first tile is reported when it is loaded)
+            per = max(1, room // max(1, len(cycle_list) + 1))
+            n_batches = max(1, -(-len(tiles) // per))
+            tb_n = max(1, -(-len(tiles) // n_batches))
+        batches += [(lane, tiles[b0:b0 + tb_n]) for b0 in range(0, len(tiles), tb_n)]
+    last_batch_of = {lane: bi for bi, (lane, _) in enumerate(batches)}
     pool = ThreadPoolExecutor(max_workers=max(1, threads))
     live = []                               # TileBatches not yet freed
     spare = []                              # finished ones whose buffers the next batch takes over
 
-    def start(chunk):
+    def start(batch):
         """Submit every load of a batch; returns at once."""
+        lane, chunk = batch
         handles = [reader.get_tile(lane, t) for t in chunk]
         n_clusters = handles[0].num_clusters
         for h in handles:
@@ -263,7 +274,7 @@ def scan_lane(sc: Scanner, reader, lane, tiles, cycle_list, mode, k, csr, wells,
             planes = [pool.submit(load_all)]
         else:
             planes = [pool.submit(load, i, c) for i, c in jobs]
-        return _Loading(chunk, handles, tb, filt + planes)
+        return _Loading((lane, chunk), handles, tb, filt + planes)
 
     def release(tb, keep=False):
         live.remove(tb)
@@ -285,7 +296,7 @@ def scan_lane(sc: Scanner, reader, lane, tiles, cycle_list, mode, k, csr, wells,
             cur = ahead.pop(0)
             cur.wait()
             _lap("batch %d: planes in HBM" % bi)
-            chunk, tb = cur.chunk, cur.tb
+            (lane, chunk), tb = cur.chunk, cur.tb
             n_clusters = tb.N
             seq_bytes = {}
             for i in range(len(chunk)):
@@ -306,7 +317,7 @@ def scan_lane(sc: Scanner, reader, lane, tiles, cycle_list, mode, k, csr, wells,
             if overlap and bi + depth < len(batches):
                 ahead.append(start(batches[bi + depth]))
             for i, t in enumerate(chunk):
-                counts[t] = report.TileCounts.from_block(blocks[i], levels)
+                counts[(lane, t)] = report.TileCounts.from_block(blocks[i], levels)
                 if want_log:
                     lines = ["Reading tile %s in lane %s" % (t, lane),
                              "Got %i sequences from %i contiguous cycle ranges." % (
@@ -320,7 +331,9 @@ def scan_lane(sc: Scanner, reader, lane, tiles, cycle_list, mode, k, csr, wells,
                         lines.append("center seq at {:>07}: {}".format(c, cs))
                         lines.append("well seq at   {:>07}: {}".format(w, ws))
                         lines.append("edit distance: {}".format(int(h["dist"])))
-                    logs[t] = lines
+                    logs[(lane, t)] = lines
+            if lane_done is not None and last_batch_of[lane] == bi:
+                lane_done(lane)
             if not overlap and bi + 1 < len(batches):
                 ahead.append(start(batches[bi + 1]))
     finally:
@@ -419,23 +432,25 @@ def main(argv=None):
                                     strict=args.strict, out=out_fh)
 
             try:
-                for lane in lanes if err is None else ():
-                    mine_here = [i for i, (ln, _) in enumerate(mine) if ln == lane]
-                    if not mine_here:
-                        continue
-                    counts, lane_logs = scan_lane(sc, reader, lane, [mine[i][1] for i in mine_here], cycle_list,
-                                                  mode, k, csr, wells,
-                                                  max(0, args.tile_batch), args.threads,
-                                                  0 if (args.quiet or args.all_wells) else len(cycles),
-                                                  overlap=not args.serial_ingest,
-                                                  interleave=4 if args.layout == "interleaved" else 1,
-                                                  gpu_inflate=not args.host_inflate)
-                    for i in mine_here:
-                        c = counts[mine[i][1]]
-                        rows[i] = [c.targets] + c.wells + c.dups + c.hit + c.first + c.last
-                    logs.update({(lane, t): lines for t, lines in lane_logs.items()})
+                lane_tiles = [(lane, [t for (ln, t) in mine if ln == lane]) for lane in lanes] if err is None else []
+                where = {item: i for i, item in enumerate(mine)}
+                results = {"counts": {}, "logs": {}}      # scan_lanes fills these, lane_done reads them
+
+                def lane_done(lane):
+                    for t in dict(lane_tiles)[lane]:
+                        c = results["counts"][(lane, t)]
+                        rows[where[(lane, t)]] = [c.targets] + c.wells + c.dups + c.hit + c.first + c.last
+                        if (lane, t) in results["logs"]:
+                            logs[(lane, t)] = results["logs"][(lane, t)]
                     if world == 1:          # as the reference: a lane is reported when it is done
                         emit(lane, rows)
+
+                scan_lanes(sc, reader, lane_tiles, cycle_list, mode, k, csr, wells,
+                           max(0, args.tile_batch), args.threads,
+                           0 if (args.quiet or args.all_wells) else len(cycles),
+                           overlap=not args.serial_ingest,
+                           interleave=4 if args.layout == "interleaved" else 1,
+                           gpu_inflate=not args.host_inflate, lane_done=lane_done, into=results)
             except Exception as e:          # noqa: BLE001 - re-raised below, on every rank
                 err = e
             if world > 1:
