@@ -265,8 +265,11 @@ struct wd_ctx {
     // times), and with a stream of their own for the chunk copies the next launch's files arrive while
     // this one decodes.  Consecutive batches take turns on two decode streams, so that the next batch's
     // workgroups move in as this batch's retire (400-file batches: 36 -> 33 ms per batch).
-    static constexpr int kInflateStreams = 2;
-    static constexpr int kInflateLaunchFiles = 1024;
+    static constexpr int kInflateStreams = 4;          // decode streams that exist; `inflate_decode_streams` of them are used
+    int inflate_decode_streams = 2;                    // option / WD_DECODE_STREAMS
+    int inflate_launch_files = 1024;                   // option / WD_LAUNCH_FILES: files per decoder launch within a batch
+    unsigned inflate_launch_seq = 0;                   // launches so far: they take the decode streams in turn
+    hipEvent_t inflate_joined[kInflateStreams] = {};   // a batch's launches on a stream are done
     size_t inflate_chunk_bytes = 16u << 20;            // option "inflate_chunk_mb" (pinning memory costs time: keep the ring small)
     InflateChunk inflate_chunks[kInflateChunks];
     size_t inflate_chunk_cap = 0;                      // bytes the chunks were allocated with
@@ -1129,6 +1132,9 @@ void wd_destroy(wd_ctx *ctx)
             (void)hipStreamSynchronize(st);
             (void)hipStreamDestroy(st);
         }
+    for (auto &ev : ctx->inflate_joined)
+        if (ev)
+            (void)hipEventDestroy(ev);
     for (auto &ev : ctx->inflate_ready)
         if (ev)
             (void)hipEventDestroy(ev);
@@ -2504,6 +2510,9 @@ int inflate_prepare(wd_ctx *ctx, wd_ctx::InflateSlot &sl, int n_chunks, size_t a
     for (auto &ev : ctx->inflate_ready)
         if (!ev && hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess)
             return WD_ERR_HIP;
+    for (auto &ev : ctx->inflate_joined)
+        if (!ev && hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess)
+            return WD_ERR_HIP;
     if (arena_bytes > sl.arena_cap) {
         (void)hipFree(sl.arena);
         sl.arena = nullptr;
@@ -2693,7 +2702,10 @@ static int load_tile_files_batch_impl(wd_ctx *ctx, int n_files, const char *cons
     int hip_rc = WD_OK;
     hipStream_t copy_stream = ctx->inflate_streams[kStreams];
     const int copy_depth = std::max(1, std::min(kChunks - 1, getenv("WD_COPY_DEPTH") ? atoi(getenv("WD_COPY_DEPTH")) : 1));
-    const int si = (int)(batch_lock.ticket % kStreams);                  // consecutive batches decode on alternate streams
+    const int n_dec = std::max(1, std::min(kStreams, getenv("WD_DECODE_STREAMS") ? atoi(getenv("WD_DECODE_STREAMS")) : ctx->inflate_decode_streams));
+    const size_t launch_files = (size_t)std::max(64, getenv("WD_LAUNCH_FILES") ? atoi(getenv("WD_LAUNCH_FILES")) : ctx->inflate_launch_files);
+    int si = (int)(ctx->inflate_launch_seq % (unsigned)n_dec);           // consecutive launches decode on the streams in turn
+    unsigned used_streams = 0;                                           // bit u: this batch launched on stream u
     size_t j0 = 0;                                                       // first job of the launch being gathered
     double wait_read_s = 0, wait_copy_s = 0;                             // (WD_INFLATE_STATS) what the chunk loop waits for
     const bool dma_probe = getenv("WD_INFLATE_STATS") && atoi(getenv("WD_INFLATE_STATS")) >= 2;
@@ -2755,10 +2767,13 @@ static int load_tile_files_batch_impl(wd_ctx *ctx, int n_files, const char *cons
         if (hip_rc != WD_OK)
             break;
         // enough files for a launch, or the last chunk: decode them
-        if (g + 1 == n_groups || job_file.size() - j0 >= (size_t)wd_ctx::kInflateLaunchFiles) {
+        if (g + 1 == n_groups || job_file.size() - j0 >= launch_files) {
             const unsigned nj = (unsigned)(job_file.size() - j0);
+            si = (int)(ctx->inflate_launch_seq % (unsigned)n_dec);
             hipStream_t stream = ctx->inflate_streams[si];
             if (nj) {
+                ctx->inflate_launch_seq++;
+                used_streams |= 1u << si;
                 if (hipEventRecord(ctx->inflate_ready[si], copy_stream) != hipSuccess ||
                     hipStreamWaitEvent(stream, ctx->inflate_ready[si], 0) != hipSuccess ||
                     hipMemcpyAsync(slot.d_jobs + j0, slot.h_jobs + j0, sizeof(InfJob) * nj,
@@ -2769,7 +2784,8 @@ static int load_tile_files_batch_impl(wd_ctx *ctx, int n_files, const char *cons
                 // waves per file: eight while every file of the launch gets a CU of its own (24 ms per
                 // file), else four (34 ms, two files per CU - three, 36 ms, when no file of the launch
                 // expands much: the small-window form); one wave per file (89 ms, three per CU) on request
-                const int waves = ctx->inflate_waves ? ctx->inflate_waves : nj <= 256 ? 8 : 4;
+                // (a launch that is one of several of its batch shares the chip with the others: four waves)
+                const int waves = ctx->inflate_waves ? ctx->inflate_waves : (nj <= 256 && n_jobs <= 256) ? 8 : 4;
                 bool slim = true;
                 for (size_t q = j0; q < job_file.size() && slim; q++) {
                     const int i = job_file[q];
@@ -2855,6 +2871,12 @@ static int load_tile_files_batch_impl(wd_ctx *ctx, int n_files, const char *cons
     }
     // the next batch may start reading; this one waits for its last results
     // (.filter copies ride on the copy stream: the decode stream's event must come after them)
+    // (the last launch's stream gathers the others the batch used, then signals the batch done)
+    for (int u = 0; u < kStreams && hip_rc == WD_OK && n_groups; u++)
+        if (u != si && (used_streams >> u & 1u) &&
+            (hipEventRecord(ctx->inflate_joined[u], ctx->inflate_streams[u]) != hipSuccess ||
+             hipStreamWaitEvent(ctx->inflate_streams[si], ctx->inflate_joined[u], 0) != hipSuccess))
+            hip_rc = WD_ERR_HIP;
     if (hip_rc == WD_OK && n_groups &&
         (hipEventRecord(ctx->inflate_ready[si], copy_stream) != hipSuccess ||
          hipStreamWaitEvent(ctx->inflate_streams[si], ctx->inflate_ready[si], 0) != hipSuccess ||
@@ -3291,7 +3313,7 @@ static int load_cbcl_batch_impl(wd_ctx *ctx, int n, const char *const *paths, co
     std::vector<int> job_file;
     job_file.reserve(n_jobs);
     int hip_rc = WD_OK;
-    const int si = (int)(batch_lock.ticket % kStreams);
+    const int si = (int)(ctx->inflate_launch_seq++ % (unsigned)std::max(1, std::min(kStreams, ctx->inflate_decode_streams)));
     hipStream_t copy_stream = ctx->inflate_streams[kStreams], stream = ctx->inflate_streams[si];
     for (int g = 0; g < n_groups && hip_rc == WD_OK; g++) {
         Group &grp = *groups[(size_t)g];
