@@ -70,7 +70,8 @@ def parse(argv=None):
     ap.add_argument("-k", type=int, default=0, help="distance threshold (hamming / levenshtein)")
     ap.add_argument("--no-early-exit", action="store_true",
                     help="full gather: read all L bytes of every neighbour")
-    ap.add_argument("--cpu-tiles", type=int, default=8, help="tiles in the CPU-baseline sample")
+    ap.add_argument("--cpu-tiles", type=int, default=16,
+                    help="tiles in the CPU-baseline sample (one thread per tile, up to the CPUs this process may use)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-steps", type=int, default=20)
     ap.add_argument("--interleaved-tiles", type=int, default=96,
@@ -841,7 +842,14 @@ def main(argv=None):
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import oracle
         n_cpu = max(1, min(args.cpu_tiles, args.tiles))
-        cores = max(1, min(16, os.cpu_count() or 1, n_cpu))
+        usable = os.cpu_count() or 1
+        try:                                                  # (the cgroup's quota, where there is one)
+            quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+            if quota != "max":
+                usable = min(usable, max(1, int(quota) // int(period)))
+        except (OSError, ValueError):
+            pass
+        cores = max(1, min(32, usable, n_cpu))
         planes = [[tb.download_plane(i, c) for c in range(L)] for i in range(n_cpu)]
         filters = [tb.download_filter(i) for i in range(n_cpu)]
         reps, t_cpu, out = 0, 0.0, None
