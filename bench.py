@@ -443,6 +443,18 @@ def e2e_probe(device, n_tiles, rows, cols, centre, lvl_off, nbr, cycles=50, thre
         run(["--host-inflate"])
         host, text_h = min(run(["--host-inflate"]) for _ in range(2))
         inter, text_i = min(run(["--layout", "interleaved"]) for _ in range(2))
+        # ... and as the reference runs by default: with the three stderr lines per duplicate (:260-262)
+        import contextlib
+        argv_log = [a for a in argv if a != "-q"]
+
+        def run_logged():
+            buf, err = io.StringIO(), io.StringIO()
+            t1 = time.perf_counter()
+            with redirect_stdout(buf), contextlib.redirect_stderr(err):
+                cwd.main(argv_log)
+            return time.perf_counter() - t1, buf.getvalue(), err.getvalue().count("edit distance:")
+        run_logged()
+        logged, text_l, dup_lines = min(run_logged() for _ in range(2))
         plane_bytes = n_tiles * cycles * n
         # the loaders alone on the same files: every .bcl.gz of the run directory into HBM, by the GPU
         # decoder (wd_load_bcl_gz_batch) and by the host threads (wd_load_bcl_gz), no scan, no report
@@ -491,7 +503,8 @@ def e2e_probe(device, n_tiles, rows, cols, centre, lvl_off, nbr, cycles=50, thre
                 "gpu_inflate_gain": round(host / best, 3) if best > 0 else None,
                 "ingest_only": ingest,
                 "interleaved_layout_seconds": round(inter, 4),
-                "same_report": text == text_s == text_i == text_h, "run_dir_write_s": round(write_s, 1),
+                "with_duplicate_log_seconds": round(logged, 4), "duplicates_logged": dup_lines,
+                "same_report": text == text_s == text_i == text_h == text_l, "run_dir_write_s": round(write_s, 1),
                 "reference_s_per_tile": 7.9,
                 "reference_note": "unmodified reference, 1 core, same geometry, --hamming -e 0 (BASELINE.md; measured in "
                                   "the build container, not on this box)"}

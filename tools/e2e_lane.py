@@ -12,7 +12,7 @@ import sys
 import tempfile
 import time
 from concurrent.futures import ThreadPoolExecutor
-from contextlib import redirect_stdout
+from contextlib import redirect_stderr, redirect_stdout
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from well_duplicates_amd import count_well_duplicates as cwd  # noqa: E402
@@ -74,15 +74,21 @@ try:
           % (n_tiles * cycles, gz[0] / 1e9, n_tiles * cycles * n / 1e9, threads, os.cpu_count()), flush=True)
     argv = ["-f", tfile, "-n", "2500", "-l", "5", "-s", "hiseq_x", "-r", root,
             "-i", ",".join(str(ln) for ln in range(1, n_lanes + 1)), "-t", ",".join(tiles),
-            "--cycles", "0-%d" % cycles, "-q", "-S", "--threads", str(threads)]
+            "--cycles", "0-%d" % cycles, "-S", "--threads", str(threads)]
+    if not os.environ.get("WD_LANE_LOG"):        # WD_LANE_LOG=1: with the stderr log of duplicates, the reference's default
+        argv.append("-q")
 
     def run(extra):
         import resource
         buf = io.StringIO()
         r0 = resource.getrusage(resource.RUSAGE_SELF)
         t1 = time.perf_counter()
-        with redirect_stdout(buf):
+        err = io.StringIO()
+        with redirect_stdout(buf), redirect_stderr(err):
             cwd.main(argv + extra)
+        for line in err.getvalue().splitlines():
+            if line.startswith("[wd "):            # WD_CLI_TIMING / WD_INFLATE_STATS lines, not the duplicate log
+                print(line)
         dt = time.perf_counter() - t1
         r1 = resource.getrusage(resource.RUSAGE_SELF)
         print("    run %s: %.3f s wall, cpu %.2f s user + %.2f s system"

@@ -155,6 +155,13 @@ def _decode(seq_bytes: np.ndarray) -> str:
     return lut[np.where(seq_bytes == 0, 0, (seq_bytes & 3) + 1)].tobytes().decode()
 
 
+def _decode_rows(rows: np.ndarray):
+    """[n, L] BCL bytes -> n strings."""
+    lut = np.frombuffer(b"NACGT", dtype="S1")
+    codes = lut[np.where(rows == 0, 0, (rows & 3) + 1)]
+    return [r.tobytes().decode() for r in codes]
+
+
 class _Loading:
     """One batch of tiles on its way into HBM: the TileBatch and the loader pool's futures."""
 
@@ -298,21 +305,23 @@ def scan_lanes(sc: Scanner, reader, lane_tiles, cycle_list, mode, k, csr, wells,
             _lap("batch %d: planes in HBM" % bi)
             (lane, chunk), tb = cur.chunk, cur.tb
             n_clusters = tb.N
-            seq_bytes = {}
-            for i in range(len(chunk)):
-                if want_log and wells.size:
-                    # only the bytes of wells some target touches come back, for the stderr log
-                    seq_bytes[i] = sc.gather_wells_batch(tb, i, wells)
             if want_log:
                 sc.hitlog_enable(max(1024, int(nbr.size) * len(chunk)))
             blocks, _ = tb.count(mode, k)
             _lap("batch %d: scanned" % bi)
-            hits = None
+            hits, seq_bytes, seq_wells = None, {}, {}
             if want_log:
                 hits, total = sc.hitlog_fetch(max(1024, int(nbr.size) * len(chunk)))
                 sc.hitlog_enable(0)
                 order = np.lexsort((hits["slot"], hits["target"], hits["tile"]))
                 hits = hits[order]
+                # the bytes of the wells that figure in a duplicate come back, for the stderr log (:260-262):
+                # a few hundred per tile, not the 200 000 some target touches
+                for i in np.unique(hits["tile"]):
+                    sel = hits[hits["tile"] == i]
+                    ws = np.unique(np.concatenate([centre[sel["target"]], nbr[sel["slot"]]]).astype(np.int64))
+                    seq_wells[int(i)] = ws
+                    seq_bytes[int(i)] = sc.gather_wells_batch(tb, int(i), ws)
             release(tb, keep=bi + depth < len(batches))
             if overlap and bi + depth < len(batches):
                 ahead.append(start(batches[bi + depth]))
@@ -323,14 +332,17 @@ def scan_lanes(sc: Scanner, reader, lane_tiles, cycle_list, mode, k, csr, wells,
                              "Got %i sequences from %i contiguous cycle ranges." % (
                                  wells.size * want_log, want_log)]
                     sel = hits[hits["tile"] == i]
-                    sb = seq_bytes.get(i)
-                    for h in sel:
-                        c, w = int(centre[h["target"]]), int(nbr[h["slot"]])
-                        cs = _decode(sb[np.searchsorted(wells, c)])
-                        ws = _decode(sb[np.searchsorted(wells, w)])
-                        lines.append("center seq at {:>07}: {}".format(c, cs))
-                        lines.append("well seq at   {:>07}: {}".format(w, ws))
-                        lines.append("edit distance: {}".format(int(h["dist"])))
+                    if sel.size:
+                        # every well of the tile's duplicates decoded once, the three lines per duplicate
+                        # (:260-262) put together from those strings
+                        sb, sw = seq_bytes[i], seq_wells[i]
+                        seqs = _decode_rows(sb)
+                        cw, ww = centre[sel["target"]].astype(np.int64), nbr[sel["slot"]].astype(np.int64)
+                        ci, wi = np.searchsorted(sw, cw), np.searchsorted(sw, ww)
+                        for c, w, a, b, d in zip(cw.tolist(), ww.tolist(), ci.tolist(), wi.tolist(), sel["dist"].tolist()):
+                            lines.append("center seq at {:>07}: {}".format(c, seqs[a]))
+                            lines.append("well seq at   {:>07}: {}".format(w, seqs[b]))
+                            lines.append("edit distance: {}".format(d))
                     logs[(lane, t)] = lines
             if lane_done is not None and last_batch_of[lane] == bi:
                 lane_done(lane)
@@ -426,8 +438,9 @@ def main(argv=None):
             def emit(lane, block):          # a finished lane: its log lines, then its report (:269)
                 counts = {t: report.TileCounts.from_block(block[pos[(lane, t)]], levels) for t in tiles}
                 for t in tiles:
-                    for line in logs.get((lane, t), ()):
-                        log(line)
+                    lines = logs.get((lane, t))
+                    if lines:
+                        log("\n".join(lines))
                 report.write_report(lane, n_targets, counts, verbose=not args.summary_only,
                                     strict=args.strict, out=out_fh)
 

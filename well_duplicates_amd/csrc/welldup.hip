@@ -221,6 +221,9 @@ struct wd_ctx {
     wd_hit *d_hits = nullptr;
     unsigned long long *d_hit_count = nullptr;
     int64_t hit_cap = 0;
+    uint8_t *d_gather = nullptr;               // wd_gather_wells' workspace (grow-only)
+    size_t gather_cap = 0;
+    size_t hit_alloc = 0;                      // records d_hits has room for (>= hit_cap: the buffer only grows)
 
     // profile
     std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
@@ -1126,6 +1129,7 @@ void wd_destroy(wd_ctx *ctx)
     (void)hipFree(ctx->d_stage);
     (void)hipFree(ctx->d_out_pt);
     (void)hipFree(ctx->d_hits);
+    (void)hipFree(ctx->d_gather);
     (void)hipFree(ctx->d_hit_count);
     for (auto &st : ctx->inflate_streams)
         if (st) {
@@ -1776,14 +1780,19 @@ try {
         return WD_ERR_ARG;
     if (bind_device(ctx))
         return WD_ERR_HIP;
-    WD_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    (void)hipFree(ctx->d_hits);
-    ctx->d_hits = nullptr;
-    ctx->hit_cap = 0;
-    if (capacity > 0) {
+    // The buffer only grows: a caller that switches the log on and off around every batch (the CLI does)
+    // must not pay a hipFree - which waits for every kernel in flight on the device, the decoder's
+    // included - and a hipMalloc each time.  Capacity 0 switches the log off and keeps the memory.
+    if ((size_t)capacity > ctx->hit_alloc) {
+        WD_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        (void)hipFree(ctx->d_hits);
+        ctx->d_hits = nullptr;
+        ctx->hit_alloc = 0;
+        ctx->hit_cap = 0;
         WD_HIP(ctx, hipMalloc((void **)&ctx->d_hits, (size_t)capacity * sizeof(wd_hit)));
-        ctx->hit_cap = capacity;
+        ctx->hit_alloc = (size_t)capacity;
     }
+    ctx->hit_cap = capacity;
     WD_HIP(ctx, hipMemsetAsync(ctx->d_hit_count, 0, sizeof(unsigned long long), ctx->stream));
     return WD_OK;
 } WD_CATCH
@@ -3464,18 +3473,23 @@ try {
         return WD_OK;
     if (bind_device(ctx))
         return WD_ERR_HIP;
-    const uint8_t **d_pl = nullptr;
-    int32_t *d_idx = nullptr;
-    uint8_t *d_out = nullptr;
-    int rc = WD_OK;
-    auto done = [&](int code, const char *msg) {
-        (void)hipFree(d_pl); (void)hipFree(d_idx); (void)hipFree(d_out);
-        return code == WD_OK ? WD_OK : fail(ctx, code, msg);
-    };
-    if (hipMalloc((void **)&d_pl, (size_t)L * sizeof(void *)) != hipSuccess ||
-        hipMalloc((void **)&d_idx, (size_t)n * 4) != hipSuccess ||
-        hipMalloc((void **)&d_out, (size_t)n * L) != hipSuccess)
-        return done(WD_ERR_NOMEM, "gather workspace");
+    // a workspace that only grows: a hipFree per call would wait for every kernel in flight on the device
+    // (the CLI calls this per tile, with the decoder of the next batches running)
+    const size_t need = (((size_t)L * sizeof(void *) + 255) & ~(size_t)255) + (((size_t)n * 4 + 255) & ~(size_t)255) + (size_t)n * L;
+    if (need > ctx->gather_cap) {
+        WD_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        (void)hipFree(ctx->d_gather);
+        ctx->d_gather = nullptr;
+        ctx->gather_cap = 0;
+        const size_t want = need + (need >> 1) + 4096;
+        if (hipMalloc((void **)&ctx->d_gather, want) != hipSuccess)
+            return fail(ctx, WD_ERR_NOMEM, "gather workspace");
+        ctx->gather_cap = want;
+    }
+    const uint8_t **d_pl = (const uint8_t **)ctx->d_gather;
+    int32_t *d_idx = (int32_t *)(ctx->d_gather + (((size_t)L * sizeof(void *) + 255) & ~(size_t)255));
+    uint8_t *d_out = (uint8_t *)d_idx + (((size_t)n * 4 + 255) & ~(size_t)255);
+    auto done = [&](int code, const char *msg) { return code == WD_OK ? WD_OK : fail(ctx, code, msg); };
     if (hipMemcpyAsync(d_pl, planes, (size_t)L * sizeof(void *), hipMemcpyHostToDevice, ctx->stream) != hipSuccess ||
         hipMemcpyAsync(d_idx, idx, (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream) != hipSuccess)
         return done(WD_ERR_HIP, "gather upload");
@@ -3486,7 +3500,6 @@ try {
         hipMemcpyAsync(out_host, d_out, (size_t)total, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
         hipStreamSynchronize(ctx->stream) != hipSuccess)
         return done(WD_ERR_HIP, "gather kernel");
-    (void)rc;
     return done(WD_OK, "");
 } WD_CATCH
 

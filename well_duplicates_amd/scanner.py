@@ -336,12 +336,15 @@ class Scanner:
         self._ck(self._lib.wd_hitlog_enable(self._ctx, int(capacity)))
 
     def hitlog_fetch(self, max_records: int):
-        buf = (_lib.Hit * max(1, max_records))()
+        """-> (records of the last scan as a structured array, total number found).  The count is read
+        first, so the host buffer is as large as the records there are, not as the log could hold."""
         total = ctypes.c_int64()
-        self._ck(self._lib.wd_hitlog_fetch(self._ctx, buf, max_records, ctypes.byref(total)))
-        n = min(total.value, max_records)
-        recs = np.frombuffer(buf, dtype=np.dtype([("tile", "<i4"), ("target", "<i4"),
-                                                  ("slot", "<i4"), ("dist", "<i4")]), count=n).copy()
+        self._ck(self._lib.wd_hitlog_fetch(self._ctx, None, 0, ctypes.byref(total)))
+        n = max(0, min(total.value, int(max_records)))
+        dt = np.dtype([("tile", "<i4"), ("target", "<i4"), ("slot", "<i4"), ("dist", "<i4")])
+        recs = np.zeros(n, dtype=dt)
+        if n:
+            self._ck(self._lib.wd_hitlog_fetch(self._ctx, recs.ctypes.data_as(ctypes.c_void_p), n, ctypes.byref(total)))
         return recs, total.value
 
     def profile_get(self):
