@@ -77,6 +77,11 @@ try:
             "--cycles", "0-%d" % cycles, "-S", "--threads", str(threads)]
     if not os.environ.get("WD_LANE_LOG"):        # WD_LANE_LOG=1: with the stderr log of duplicates, the reference's default
         argv.append("-q")
+    if os.environ.get("WD_LANE_ALL_WELLS"):      # every well a centre (3 levels, rings from the run's s.locs): the dense path
+        x, y = synth.honeycomb_pixels(rows, cols)
+        with open(os.path.join(root, "Data", "Intensities", "s.locs"), "wb") as fh:
+            fh.write(synth.slocs_bytes(x, y))
+        argv = ["--all-wells", "-l", "3"] + argv[6:]
 
     def run(extra):
         import resource
