@@ -20,8 +20,9 @@ performed compare = one unit of the reference report's `Wells` column
 Extra objects on the JSON line:
   roofline      HBM roofline of the dominant kernel (k_scan_q): algorithmic bytes
                 B = C*(L+4) + Tv*(L+5) + 8*(1+5*levels)*tiles per launch over the
-                kernel's mean duration, measured with HIP events on the launch stream around at
-                least 16 launches of the timed region itself; `traffic` = HBM bytes per launch from
+                kernel's mean duration, measured with HIP events on the launch stream around every
+                n-th launch of the timed region itself (n = 4 at 20 steps: events around every launch
+                cost the step 6 %), `region_ms_per_launch` = one event pair around the whole region; `traffic` = HBM bytes per launch from
                 the PMC counters of the same kernel on the same workload (profiles/traffic.json,
                 `traffic_source` says which run - null if that run profiled another kernel than the one
                 this run launched), `l2_miss_frac` = traffic / kernel time / peak (L2-miss bytes: the
@@ -662,16 +663,22 @@ def main(argv=None):
 
     run(args.warmup)
     sc.scan_status()
-    # HIP events around every n-th scan launch of the timed region, on the launch stream, at least
-    # 16 of them: the roofline's kernel time comes from launches that `value` is made of (every
-    # launch would cost the step 3-5 % in event records)
-    sc.set_option("profile", max(1, min(8, args.steps // 16)))
+    # HIP events around every n-th scan launch of the timed region, on the launch stream (a pair of event
+    # records around EVERY launch costs the step 6 % - measured: 0.1355 against 0.1278 ms at 20 steps - so
+    # at the driver's 20 steps every fourth launch is timed, at 200 every eighth: 5 and 25 launches), and
+    # one more pair around the whole region on the same stream: the GPU-side time of all K launches
+    # with their counter memsets, the cross-check of the per-launch figure
+    sc.set_option("profile", int(os.environ.get("WD_BENCH_PROFILE_EVERY", 0)) or max(1, min(8, args.steps // 5)))
     sc.profile_reset()
+    region = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
     fence()
     t_start = time.perf_counter()
+    region[0].record(stream)
     block = run(args.steps)
+    region[1].record(stream)
     fence()
     elapsed = time.perf_counter() - t_start
+    region_ms = region[0].elapsed_time(region[1]) / max(1, args.steps)
     kern_ms_total, launches = sc.profile_get()
     headline_kernel = sc.last_kernel()
     sc.set_option("profile", 0)
@@ -846,6 +853,7 @@ def main(argv=None):
                 "two_lanes_alternating": two_lanes,
                 "algorithmic_bytes_per_launch": b_alg,
                 "kernel_ms": round(kern_ms, 5), "launches_timed": launches,
+                "region_ms_per_launch": round(region_ms, 5),
                 "units_per_launch": compares_rank,
                 "full_gather_kernel_ms": None if worst is None else round(worst, 5),
                 "full_gather_alg_bytes_over_peak": None if not worst else round(b_alg / (worst * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
