@@ -43,6 +43,7 @@ def test_dense_path_vs_oracle_on_sampled_centres(setup):
         sc.set_option("dense_kernel", -1)
         blocks, pt = tb.count(mode, k, per_target=True)
         assert sc.last_kernel().startswith("dense chain"), sc.last_kernel()
+        assert "pairs from one end" in sc.last_kernel()        # rings cut out of distances are symmetric: each pair compared once
         assert sc.get_option("dense_window_groups") >= (n + 63) // 64 - 1      # compared from LDS windows
         got_all = pt[0].astype(np.int64)
         got_all[got_all == INVALID_TARGET] = -1

@@ -117,14 +117,19 @@ def test_fuzz(seed):
 N_WIN_SEEDS = int(os.environ.get("WD_FUZZ_WINDOW_SEEDS", "10"))
 
 
-def _grid_targets(rng, rows, cols, c_first, T, levels, n_off, p_drop, p_flip, p_mess):
+def _grid_targets(rng, rows, cols, c_first, T, levels, n_off, p_drop, p_flip, p_mess, symmetric=False):
     offs = set()
     while len(offs) < n_off:
         dr, dc = int(rng.integers(-3, 4)), int(rng.integers(-7, 8))
         if (dr, dc) != (0, 0):
             offs.add((dr, dc))
+            if symmetric:                                  # b in a's ring r <=> a in b's ring r, as rings cut out of distances are
+                offs.add((-dr, -dc))
     offs = sorted(offs)
     base_level = {o: int(rng.integers(0, levels)) for o in offs}
+    if symmetric:
+        for o in offs:
+            base_level[(-o[0], -o[1])] = base_level[o]
     n = rows * cols
     centre = np.arange(c_first, c_first + T, dtype=np.int32)
     lvl_off = np.zeros((T, levels + 1), dtype=np.int32)
@@ -167,8 +172,23 @@ def test_fuzz_window_groups(seed):
     T = max(1, min(T, n))
     c_first = int(rng.integers(0, n - T + 1))
     p_mess, p_flip = float(rng.choice([0.0, 0.0, 0.003])), float(rng.choice([0.0, 0.05]))
+    p_drop = float(rng.choice([0.0, 0.02, 0.3]))
+    # every third seed: every well a centre and a symmetric neighbour relation - the dense path then compares
+    # each pair from its lower well only and records a duplicate at both ends (option dense_sym)
+    symmetric = seed % 3 == 1
+    if symmetric:
+        T, c_first, p_mess, p_flip, p_drop = n, 0, 0.0, 0.0, 0.0
     centre, lvl_off, nbr = _grid_targets(rng, rows, cols, c_first, T, levels, int(rng.choice([4, 12, 36, 60, 90])),
-                                         float(rng.choice([0.0, 0.02, 0.3])), p_flip, p_mess)
+                                         p_drop, p_flip, p_mess, symmetric)
+    pairs = {}
+    for t in range(T):
+        for l in range(levels):
+            for w in nbr[lvl_off[t, l]:lvl_off[t, l + 1]]:
+                pairs[(int(centre[t]), int(w))] = pairs.get((int(centre[t]), int(w)), ()) + (l,)
+    # what k_dense_symcheck establishes: consecutive centres, every neighbour a centre, each pair once and in
+    # the same ring from both ends
+    is_sym = T >= 2 and all(c_first <= w < c_first + T and w != c and len(v) == 1 and pairs.get((w, c)) == v
+                            for (c, w), v in pairs.items())
     spec = synth.SynthSpec(seed=300 + seed, n_clusters=n, row=cols,
                            plant_per_64k=int(rng.choice([0, 2000, 20000, 65536])),
                            nocall_per_64k=int(rng.choice([0, 300, 5000])),
@@ -197,10 +217,12 @@ def test_fuzz_window_groups(seed):
                             "dense_pack": int(rng.choice([-1, 0, 1])) if trial else -1,
                             "dense_overlap": int(rng.integers(0, 2)) if trial else 0,
                             "dense_part_tiles": int(rng.choice([0, 1, 2, 3])),
-                            "dense_pack_blocks": int(rng.choice([0, 7, 1024]))}
+                            "dense_pack_blocks": int(rng.choice([0, 7, 1024])),
+                            "dense_sym": int(rng.integers(0, 2)) if trial else 1}
                     for name, v in opts.items():
                         sc.set_option(name, v)
                     blocks, pt = tb.count(mode, k, per_target=True)
+                    assert sc.get_option("dense_sym_on") == (1 if is_sym and opts["dense_sym"] else 0), (seed, opts, is_sym)
                     # clean input (with ring flips a union of (ring, offset) pairs may outgrow the 128
                     # elements a window group holds): the path under test is the one that ran
                     if p_mess == 0.0 and p_flip == 0.0 and T >= 128:

@@ -16,7 +16,7 @@ pytestmark = pytest.mark.gpu
 
 DEFAULT_OPTIONS = (("early_exit", 1), ("batch_first", 4), ("batch_next", 4), ("targets_per_block", 32),
                    ("queue_kernel", 1), ("queue_first", 0), ("dense_kernel", -1), ("dense_pack", -1),
-                   ("dense_queue_cap", 0))
+                   ("dense_queue_cap", 0), ("dense_sym", 1))
 
 
 @pytest.fixture(scope="module")
@@ -421,9 +421,13 @@ def test_errors_and_edges(sc):
     tb.free()
 
 
-def test_dense_all_centres_small(sc):
-    """BASELINE config 5 in small: every well of a tile is a centre, 3 levels, 150 bp."""
+@pytest.mark.parametrize("sym", [1, 0])
+def test_dense_all_centres_small(sc, sym):
+    """BASELINE config 5 in small: every well of a tile is a centre, 3 levels, 150 bp.  sym = 1: the
+    neighbour relation is symmetric, so every pair is compared from its lower well only and a duplicate
+    recorded at both ends (the default); sym = 0: every pair from both ends, as for sampled targets."""
     from well_duplicates_amd import workload
+    sc.set_option("dense_sym", sym)
     rows, cols, levels, L = 40, 60, 3, 150
     n = rows * cols
     x, y = synth.honeycomb_pixels(rows, cols)
@@ -441,6 +445,8 @@ def test_dense_all_centres_small(sc):
         sc.set_option("dense_kernel", dense)      # lane-per-target path vs the queue kernel
         sc.set_option("dense_pack", pack)         # survivors checked on packed rows / on the planes
         blocks, pt = tb.count(mode, k, per_target=True)
+        if dense:
+            assert sc.get_option("dense_sym_on") == sym
         sc.set_option("dense_kernel", -1)
         sc.set_option("dense_pack", -1)
         for i, (lane, tile) in enumerate(tiles):
@@ -463,10 +469,12 @@ def test_dense_all_centres_small(sc):
         sc.set_option("dense_kernel", -1)
         assert (blocks == want[(mode, k)][0]).all() and (pt == want[(mode, k)][1]).all()
     tb.free()
+    sc.set_option("dense_sym", 1)
 
 
+@pytest.mark.parametrize("sym", [1, 0])
 @pytest.mark.parametrize("L", [150, 24, 17])
-def test_dense_window_groups(sc, L):
+def test_dense_window_groups(sc, L, sym):
     """A grid wide enough (200 wells per row) that most 64-target groups lie inside one row: the
     dense path scans them through LDS windows of their neighbours' signatures (k_dense_windows,
     k_dense_pairs) and settles the survivors on packed rows of the marked wells only.  Every mode
@@ -479,6 +487,7 @@ def test_dense_window_groups(sc, L):
     centre, lvl_off, nbr = workload.targets_to_csr(cluster_indexes.generate(x, y, range(n), levels))
     spec = synth.SynthSpec(seed=21 + L, n_clusters=n, row=cols, plant_per_64k=3000, plant_far=True,
                            nocall_per_64k=1500)
+    sc.set_option("dense_sym", sym)          # pairs from their lower well only (the default) / from both ends
     sc.set_targets(centre, lvl_off, nbr)
     tiles = [(1, 1101), (2, 1205), (3, 2101)]
     tb = TileBatch(sc, len(tiles), L, n)
@@ -495,7 +504,7 @@ def test_dense_window_groups(sc, L):
             sc.hitlog_enable(0)
             groups = (n + 63) // 64
             assert sc.get_option("dense_window_groups") > groups // 4        # the path under test ran
-            assert sc.get_option("dense_window_groups") < groups             # and so did the gather path
+            assert sc.get_option("dense_sym_on") == sym
             want_hits = []
             for i in range(len(tiles)):
                 planes, filt = host[i]
@@ -524,6 +533,7 @@ def test_dense_window_groups(sc, L):
         sc.set_option("dense_kernel", -1)
         sc.set_option("dense_pack", -1)
         sc.set_option("dense_queue_cap", 0)
+        sc.set_option("dense_sym", 1)
         tb.free()
 
 

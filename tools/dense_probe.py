@@ -17,11 +17,13 @@ ap.add_argument("--mode", type=int, default=0)
 ap.add_argument("-k", type=int, default=0)
 ap.add_argument("--chunk", default="4", help="comma list of dense_tile_chunk values to time")
 ap.add_argument("--pack", type=int, default=-1, help="dense_pack option: -1 auto, 0 never, 1 always")
+ap.add_argument("--sym", type=int, default=1, help="dense_sym option: 1 = pairs compared from their lower well only")
 ap.add_argument("--plant", type=int, default=1311, help="planted wells per 65536 (1311 = 2 %%)")
 a = ap.parse_args()
 n = a.rows * a.cols
 x, y = synth.honeycomb_pixels(a.rows, a.cols)
 sc = Scanner(0)
+sc.set_option("dense_sym", a.sym)
 t0 = time.time()
 T, P = sc.targets_from_coords(x, y, None, levels=a.levels)
 print("generator: %d centres, %d slots (%.1f per centre) in %.2f s" % (T, P, P / T, time.time() - t0))
@@ -40,5 +42,6 @@ for ch in [int(v) for v in a.chunk.split(",")] * 2:
     blk = sc.d2h(out, a.tiles * (1 + 5 * a.levels) * 8, np.int64).reshape(a.tiles, -1)
     C = int(blk[:, 1:1 + a.levels].sum()); Tv = int(blk[:, 0].sum())
     b_dense = a.tiles * (n * a.bases + 4 * n * (1 + P / T) + n)
+    print(sc.last_kernel())
     print("scan: %.3f ms for %d tiles, %d compares -> %.1f Gcmp/s; dense B_alg %.2f GB -> %.0f GB/s"
           % (ms, a.tiles, C, C / ms / 1e6, b_dense / 1e9, b_dense / ms / 1e6))

@@ -190,6 +190,10 @@ struct wd_ctx {
     int32_t *d_wdelta = nullptr;      // ... the union's offsets
     uint8_t *d_wlev = nullptr;        // ... and rings
     uint32_t *d_wmask = nullptr;      // ... which elements each target has
+    uint8_t *d_wfull = nullptr;       // ... place in the whole union of the elements the compare stage walks
+    int dense_sym = 1;                // option: a symmetric neighbour relation (every well a centre) is compared from one end
+    bool dense_sym_on = false;        // the tables built last are those of the one-ended compare
+    int32_t centre0 = 0;              // ... and target t's centre is centre0 + t
     int win_kpad = 0;                 // row length of d_uoff / d_wdelta
     int win_dwords = 0;               // largest window of any group, in dwords
     long long n_uniform_groups = -1, n_window_groups = -1;   // -1: tables not built yet
@@ -524,6 +528,8 @@ long long row_length_of(const int32_t *centre, const int32_t *lvl_off, const int
     return est[est.size() / 2];
 }
 
+void drop_dense_tables(wd_ctx *ctx);
+
 // Group bases of the transposed neighbour table from host-side ring offsets (row = levels+1).
 void set_group_bases(wd_ctx *ctx, const int32_t *lvl_off, int T, int levels)
 {
@@ -539,6 +545,12 @@ void set_group_bases(wd_ctx *ctx, const int32_t *lvl_off, int T, int levels)
         pos += (long long)kmax * kWave;
     }
     ctx->h_gbase[groups] = pos;
+    drop_dense_tables(ctx);
+}
+
+// The dense path's device tables are built on its first scan after this (ensure_dense_tables).
+void drop_dense_tables(wd_ctx *ctx)
+{
     (void)hipFree(ctx->d_nbr_t);
     (void)hipFree(ctx->d_gbase);
     (void)hipFree(ctx->d_rel_t);
@@ -550,6 +562,9 @@ void set_group_bases(wd_ctx *ctx, const int32_t *lvl_off, int T, int levels)
     (void)hipFree(ctx->d_wdelta);
     (void)hipFree(ctx->d_wlev);
     (void)hipFree(ctx->d_wmask);
+    (void)hipFree(ctx->d_wfull);
+    ctx->d_wfull = nullptr;
+    ctx->dense_sym_on = false;
     ctx->d_wlev = nullptr;
     ctx->d_udelta = nullptr;
     ctx->d_guni = nullptr;
@@ -606,6 +621,21 @@ int ensure_dense_tables(wd_ctx *ctx)
         // windows (k_dense_windows); the union of a group's offsets may be a little larger than
         // any one target's list
         // (a group that straddles the end of a grid row sees two patterns: up to twice the offsets)
+        // Is the neighbour relation symmetric (every well a centre, b in a's rings <=> a in b's)?  Then every
+        // pair is compared once, from its lower well, and recorded at both ends (DenseArgs::sym)
+        ctx->dense_sym_on = false;
+        if (ctx->dense_sym && ctx->T >= 2) {
+            WD_HIP(ctx, hipMemsetAsync(ctx->d_tblflags + 2, 0, sizeof(uint32_t), ctx->stream));
+            hipLaunchKernelGGL(k_dense_symcheck, dim3((ctx->T + kBlock - 1) / kBlock), dim3(kBlock), 0, ctx->stream,
+                               ctx->d_centre, ctx->d_lvl_off, ctx->d_nbr, ctx->T, ctx->levels, ctx->d_tblflags + 2);
+            uint32_t bad = 1;
+            int32_t c0 = 0;
+            WD_HIP(ctx, hipMemcpyAsync(&bad, ctx->d_tblflags + 2, sizeof(bad), hipMemcpyDeviceToHost, ctx->stream));
+            WD_HIP(ctx, hipMemcpyAsync(&c0, ctx->d_centre, sizeof(c0), hipMemcpyDeviceToHost, ctx->stream));
+            WD_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            ctx->dense_sym_on = bad == 0;
+            ctx->centre0 = c0;
+        }
         const int64_t kpad = std::min<int64_t>(kWinMaxK, (2 * ctx->k_max + 8 + 31) & ~(int64_t)31);
         if (ctx->k_max >= 1 && ctx->k_max <= kpad) {
             ctx->win_kpad = (int)kpad;
@@ -615,10 +645,12 @@ int ensure_dense_tables(wd_ctx *ctx)
             WD_HIP(ctx, hipMalloc((void **)&ctx->d_wdelta, (size_t)groups * kpad * sizeof(int32_t)));
             WD_HIP(ctx, hipMalloc((void **)&ctx->d_wlev, (size_t)groups * kpad));
             WD_HIP(ctx, hipMalloc((void **)&ctx->d_wmask, (size_t)groups * (kpad / 32) * kWave * sizeof(uint32_t)));
+            WD_HIP(ctx, hipMalloc((void **)&ctx->d_wfull, (size_t)groups * kpad));
             WD_HIP(ctx, hipMemsetAsync(ctx->d_ginfo, 0, (size_t)groups * sizeof(int32_t), ctx->stream));
             hipLaunchKernelGGL(k_dense_windows, dim3(groups), dim3(kWave), 0, ctx->stream, ctx->d_centre, ctx->d_lvl_off,
                                ctx->d_nbr, ctx->T, ctx->levels, ctx->win_kpad, ctx->d_ginfo, ctx->d_useg, ctx->d_uoff,
-                               ctx->d_wdelta, ctx->d_wlev, ctx->d_wmask, ctx->d_tblflags + 1);
+                               ctx->d_wdelta, ctx->d_wlev, ctx->d_wmask, ctx->d_tblflags + 1, ctx->dense_sym_on ? 1 : 0,
+                               ctx->d_wfull);
             WD_HIP(ctx, hipMemcpyAsync(flags, ctx->d_tblflags, sizeof(flags), hipMemcpyDeviceToHost, ctx->stream));
             WD_HIP(ctx, hipStreamSynchronize(ctx->stream));
             ctx->win_dwords = (int)((flags[1] + kWave - 1) / kWave * kWave);     // whole pieces of 64 dwords
@@ -800,6 +832,9 @@ int launch_dense(wd_ctx *ctx, const ScanArgs &a, int n_tiles, int64_t N, bool st
     d.wdelta = ctx->d_wdelta;
     d.wlev = ctx->d_wlev;
     d.wmask = ctx->d_wmask;
+    d.wfull = ctx->d_wfull;
+    d.sym = ctx->dense_sym_on ? 1 : 0;
+    d.centre0 = ctx->centre0;
     d.kpad = ctx->win_kpad;
     d.win_dwords = ctx->win_dwords;
     d.gbase = ctx->d_gbase;
@@ -823,9 +858,24 @@ int launch_dense(wd_ctx *ctx, const ScanArgs &a, int n_tiles, int64_t N, bool st
     const long long n_groups = (a.T + kWave - 1) / kWave;
     long long q_per = ctx->dense_queue_cap > 0 ? ctx->dense_queue_cap : (lev2 ? 32 : 16);
     // LDS of a k_dense_pairs wave: its signature windows, then 8 bytes per queue entry
-    const long long win_bytes = (long long)kWinBufs * d.win_dwords * sizeof(uint32_t);
     q_per = std::max<long long>(1, std::min<long long>(q_per, kWave));      // one queue entry per lane at most
     d.q_per = (int)q_per;
+    // (the one-ended compare keeps the windows of three tiles in flight while LDS lets five workgroups share a CU)
+    d.win_bufs = kWinBufs;
+    int npc = 0;                                        // pieces of 64 signatures per window, if the kernel is built for that many
+    if (d.sym) {
+        for (d.win_bufs = kWinBufsSym; d.win_bufs > kWinBufs; d.win_bufs--)
+            if ((size_t)kWaves * ((size_t)d.win_bufs * d.win_dwords * 4 + 4 * ((size_t)tile_chunk * (2 * q_per + 1) + 1)) <= 32 * 1024)
+                break;
+        if (d.win_bufs == kWinBufsSym && d.ginfo)
+            for (int cand : {4, 5, 6, 8})
+                if (!npc && d.win_dwords <= cand * kWave &&
+                    (size_t)kWaves * ((size_t)d.win_bufs * cand * kWave * 4 + 4 * ((size_t)tile_chunk * (2 * q_per + 1) + 1)) <= 32 * 1024)
+                    npc = cand;
+        if (npc)
+            d.win_dwords = npc * kWave;
+    }
+    const long long win_bytes = (long long)d.win_bufs * d.win_dwords * sizeof(uint32_t);
     d.mw_stride = (((N + 31) / 32) + kMarkBlock - 1) / kMarkBlock * kMarkBlock;
     // scratch of ONE part (the largest); set s of a buffer starts s parts in
     const size_t sig_words = (size_t)d.sig_stride * part * ((lev2 || a.k > 0) ? 2 : 1);
@@ -918,23 +968,51 @@ int launch_dense(wd_ctx *ctx, const ScanArgs &a, int n_tiles, int64_t N, bool st
         const size_t q_lds = (size_t)kWaves * ((size_t)win_bytes + 4 * ((size_t)tc * (2 * d.q_per + 1) + (tc & 1)));
         hipLaunchKernelGGL(k_dense_counts, dim3((unsigned)((a.T + 4 * kBlock - 1) / (4 * kBlock)), (unsigned)((nt + tc - 1) / tc)),
                            dim3(kBlock), 0, st, d);
-#define WD_LAUNCH_PAIRS(MODE)                                                                                   \
+#define WD_LAUNCH_PAIRS(MODE, SYM)                                                                              \
     do {                                                                                                        \
         if (d.ginfo)                                                                                            \
-            hipLaunchKernelGGL((k_dense_pairs_win<MODE>), grid, dim3(kBlock), q_lds, st, d);                    \
+            hipLaunchKernelGGL((k_dense_pairs_win<MODE, SYM>), grid, dim3(kBlock), q_lds, st, d);               \
         if (ctx->n_window_groups < n_groups || !d.ginfo) {                                                      \
             if (ctx->nbr_t16)                                                                                   \
-                hipLaunchKernelGGL((k_dense_pairs<MODE, true>), pgrid, dim3(kBlock), q_lds, st, d);            \
+                hipLaunchKernelGGL((k_dense_pairs<MODE, true, SYM>), pgrid, dim3(kBlock), q_lds, st, d);       \
             else                                                                                                \
-                hipLaunchKernelGGL((k_dense_pairs<MODE, false>), pgrid, dim3(kBlock), q_lds, st, d);          \
+                hipLaunchKernelGGL((k_dense_pairs<MODE, false, SYM>), pgrid, dim3(kBlock), q_lds, st, d);     \
         }                                                                                                       \
     } while (0)
-        if (pmode == 0)
-            WD_LAUNCH_PAIRS(0);
+#define WD_LAUNCH_PAIRS_N(MODE, NPC)                                                                            \
+    do {                                                                                                        \
+        hipLaunchKernelGGL((k_dense_pairs_win<MODE, true, NPC>), grid, dim3(kBlock), q_lds, st, d);             \
+        if (ctx->n_window_groups < n_groups) {                                                                  \
+            if (ctx->nbr_t16)                                                                                   \
+                hipLaunchKernelGGL((k_dense_pairs<MODE, true, true>), pgrid, dim3(kBlock), q_lds, st, d);      \
+            else                                                                                                \
+                hipLaunchKernelGGL((k_dense_pairs<MODE, false, true>), pgrid, dim3(kBlock), q_lds, st, d);    \
+        }                                                                                                       \
+    } while (0)
+#define WD_LAUNCH_PAIRS_SYM(MODE)                                                                               \
+    do {                                                                                                        \
+        switch (npc) {                                                                                          \
+        case 4: WD_LAUNCH_PAIRS_N(MODE, 4); break;                                                              \
+        case 5: WD_LAUNCH_PAIRS_N(MODE, 5); break;                                                              \
+        case 6: WD_LAUNCH_PAIRS_N(MODE, 6); break;                                                              \
+        case 8: WD_LAUNCH_PAIRS_N(MODE, 8); break;                                                              \
+        default: WD_LAUNCH_PAIRS(MODE, true); break;                                                            \
+        }                                                                                                       \
+    } while (0)
+        if (pmode == 0 && d.sym)
+            WD_LAUNCH_PAIRS_SYM(0);
+        else if (pmode == 0)
+            WD_LAUNCH_PAIRS(0, false);
+        else if (pmode == 1 && d.sym)
+            WD_LAUNCH_PAIRS_SYM(1);
         else if (pmode == 1)
-            WD_LAUNCH_PAIRS(1);
+            WD_LAUNCH_PAIRS(1, false);
+        else if (d.sym)
+            WD_LAUNCH_PAIRS_SYM(2);
         else
-            WD_LAUNCH_PAIRS(2);
+            WD_LAUNCH_PAIRS(2, false);
+#undef WD_LAUNCH_PAIRS_SYM
+#undef WD_LAUNCH_PAIRS_N
 #undef WD_LAUNCH_PAIRS
         if (lev2)
             hipLaunchKernelGGL(k_dense_mark, dim3(mark_blocks, (unsigned)nt), dim3(kBlock), 0, st, d);
@@ -1057,7 +1135,7 @@ wd_ctx *wd_create(int device_id)
     if (hipSetDevice(device_id) != hipSuccess ||
         hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking) != hipSuccess ||
         hipMalloc((void **)&ctx->d_status, sizeof(uint32_t)) != hipSuccess ||
-        hipMalloc((void **)&ctx->d_tblflags, 2 * sizeof(uint32_t)) != hipSuccess ||
+        hipMalloc((void **)&ctx->d_tblflags, 4 * sizeof(uint32_t)) != hipSuccess ||
         hipMalloc((void **)&ctx->d_rare, sizeof(ScanRare)) != hipSuccess ||
         hipHostMalloc((void **)&ctx->h_status, sizeof(uint32_t), hipHostMallocDefault) != hipSuccess ||
         hipMalloc((void **)&ctx->d_hit_count, sizeof(unsigned long long)) != hipSuccess) {
@@ -1260,6 +1338,12 @@ try {
         ctx->dense_pack = value < 0 ? -1 : (value ? 1 : 0);
     } else if (n == "dense_windows") {
         ctx->dense_windows = value ? 1 : 0;
+    } else if (n == "dense_sym") {
+        if (ctx->dense_sym != (value ? 1 : 0)) {        // the window tables are built for one or the other
+            WD_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            drop_dense_tables(ctx);
+        }
+        ctx->dense_sym = value ? 1 : 0;
     } else if (n == "dense_nt") {
         ctx->dense_nt = value ? 1 : 0;
     } else if (n == "dense_queue_cap") {
@@ -1294,6 +1378,8 @@ try {
     else if (n == "dense_queue_cap") *value = ctx->dense_queue_cap;
     else if (n == "dense_pack") *value = ctx->dense_pack;
     else if (n == "dense_windows") *value = ctx->dense_windows;
+    else if (n == "dense_sym") *value = ctx->dense_sym;
+    else if (n == "dense_sym_on") *value = ctx->dense_sym_on ? 1 : 0;      // read-only: the tables built last are one-ended
     else if (n == "dense_nt") *value = ctx->dense_nt;
     else if (n == "fast_inflate") *value = ctx->fast_inflate;
     else if (n == "inflate_chunk_mb") *value = (long long)(ctx->inflate_chunk_bytes >> 20);
@@ -1626,11 +1712,12 @@ try {
         WD_HIP(ctx, hipEventRecord(ev.first, ctx->stream));
     }
     if (use_dense) {
-        snprintf(ctx->last_kernel, sizeof(ctx->last_kernel), "dense chain v%d, %s (k_dense_sig .. k_dense_reduce)",
-                 kDenseChainVersion, lev2 ? "Levenshtein <= 2" : (kk > 0 ? "Hamming" : "equality"));
         int rc = launch_dense(ctx, a, n_tiles, N, strided, n_plane_ptrs, tile_chunk, lev2);
         if (rc)
             return rc;
+        snprintf(ctx->last_kernel, sizeof(ctx->last_kernel), "dense chain v%d, %s%s (k_dense_sig .. k_dense_reduce)",
+                 kDenseChainVersion, lev2 ? "Levenshtein <= 2" : (kk > 0 ? "Hamming" : "equality"),
+                 ctx->dense_sym_on ? ", pairs from one end" : "");
     } else if (use_queue) {
         queue_view(ctx, a);
         if (strided)
