@@ -212,7 +212,9 @@ def dense_probe(device, n_tiles, rows, cols, levels=3, bases=150):
         res = {"workload": "%d tiles x %d centres x %.1f neighbours, %d levels, %d bp, 2 %% planted"
                            % (n_tiles, T, P / T, levels, bases),
                "algorithmic_bytes": int(b_dense), "ring_generator_s": round(gen_s, 3),
-               "window_groups": sc.get_option("dense_window_groups"), "groups": (T + 63) // 64}
+               "window_groups": sc.get_option("dense_window_groups"), "groups": (T + 63) // 64,
+               # 1: the neighbour relation is symmetric, every pair is compared from its lower well only
+               "pairs_from_one_end": sc.get_option("dense_sym_on")}
         # the reference's default metric (Levenshtein <= 2), Hamming <= 2, then equality for the counters
         for name, mode, k, case in (("levenshtein_k2", MODE_LEVENSHTEIN, 2, "dense_lev2"),
                                     ("hamming_k2", MODE_HAMMING, 2, "dense_ham2"), ("equality", MODE_EQ, 0, "dense_eq")):

@@ -185,10 +185,11 @@ def test_fuzz_window_groups(seed):
         for l in range(levels):
             for w in nbr[lvl_off[t, l]:lvl_off[t, l + 1]]:
                 pairs[(int(centre[t]), int(w))] = pairs.get((int(centre[t]), int(w)), ()) + (l,)
-    # what k_dense_symcheck establishes: consecutive centres, every neighbour a centre, each pair once and in
-    # the same ring from both ends
-    is_sym = T >= 2 and all(c_first <= w < c_first + T and w != c and len(v) == 1 and pairs.get((w, c)) == v
-                            for (c, w), v in pairs.items())
+    # what k_dense_symcheck establishes: consecutive centres, every neighbour a centre, rings in strictly
+    # ascending order, b in ring r of a exactly when a in ring r of b
+    ascending = all((np.diff(nbr[lvl_off[t, l]:lvl_off[t, l + 1]]) > 0).all() for t in range(T) for l in range(levels))
+    is_sym = T >= 2 and ascending and all(c_first <= w < c_first + T and w != c and pairs.get((w, c)) == v
+                                          for (c, w), v in pairs.items())
     spec = synth.SynthSpec(seed=300 + seed, n_clusters=n, row=cols,
                            plant_per_64k=int(rng.choice([0, 2000, 20000, 65536])),
                            nocall_per_64k=int(rng.choice([0, 300, 5000])),

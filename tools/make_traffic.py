@@ -17,7 +17,7 @@ import os
 import re
 
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SKIP = ("k_gen_rings", "k_transpose", "k_dense_windows", "k_synth", "k_interleave4")
+SKIP = ("k_gen_rings", "k_transpose", "k_dense_windows", "k_dense_symcheck", "k_synth", "k_interleave4")
 
 
 def main():
