@@ -233,6 +233,7 @@ def scan_lanes(sc: Scanner, reader, lane_tiles, cycle_list, mode, k, csr, wells,
         tb = TileBatch(sc, len(chunk), len(cycle_list), n_clusters, interleave=interleave,
                        reuse=spare.pop() if spare else None)
         live.append(tb)
+        _lap("  batch of %d tiles: buffers" % len(chunk))
         # ingest: every (tile, cycle) file is gunzipped into pinned memory and copied to the GPU
         # by libwelldup (wd_load_bcl_gz).  Runs without .bcl.gz files are NovaSeq runs: the
         # tile's block of the lane/surface .cbcl is gunzipped on the host and expanded on the
@@ -365,6 +366,41 @@ def main(argv=None):
     args = parse_args(argv)
     log = (lambda msg: None) if args.quiet else (lambda msg: print(str(msg), file=sys.stderr))
 
+    # The GPU context first (this thread's current device is its device from here on), so that the batch
+    # loaders' pinned ring - pinning 64 MB takes 25 ms - can be set up by a thread of its own while this one
+    # parses the targets file and lists the run directory (the call releases the GIL).  Whatever goes wrong
+    # here is raised where the scanner is needed: under torchrun that is inside the ranks' failure protocol.
+    from . import dist as wdist
+    rank, world, local_rank = wdist.env_rank()
+    device = args.device if args.device is not None else (local_rank if world > 1 else 0)
+    early = {"sc": None, "err": None}
+    import threading
+    opener = None
+    try:
+        early["sc"] = Scanner(device)
+        if os.environ.get("WD_INFLATE_CHUNK_MB"):            # (measurements: the pinned ring's chunk size)
+            early["sc"].set_option("inflate_chunk_mb", int(os.environ["WD_INFLATE_CHUNK_MB"]))
+        if not args.host_inflate:
+            def warm():
+                try:
+                    early["sc"].set_option("inflate_warm", 1)
+                except Exception as e:          # noqa: BLE001
+                    early["err"] = e
+            opener = threading.Thread(target=warm, name="wd-ingest-warm-up")
+            opener.start()
+    except Exception as e:                      # noqa: BLE001
+        early["err"] = e
+    try:
+        return _main(args, log, wdist, rank, world, device, opener, early)
+    finally:
+        if opener is not None:
+            opener.join()
+        if early["sc"] is not None:
+            early["sc"].close()                 # (a second close is a no-op)
+
+
+def _main(args, log, wdist, rank, world, device, opener, early):
+
     lanes = args.lane.split(",") if args.lane else range(1, 8 + 1)
     tiles = workload.tiles_for_stype(args.stype)
     if args.tile_id:
@@ -392,9 +428,6 @@ def main(argv=None):
     reader = bcl_direct_reader.BCLReader(args.run)
     _lap("targets file, run directory")
 
-    from . import dist as wdist
-    rank, world, local_rank = wdist.env_rank()
-    device = args.device if args.device is not None else (local_rank if world > 1 else 0)
     if world > 1:
         import torch
         import torch.distributed as tdist
@@ -410,7 +443,11 @@ def main(argv=None):
         # not leave the others waiting in the first collective: setup and scan feed ONE failure flag
         sc, err = None, None
         try:
-            sc = Scanner(device)
+            if opener is not None:
+                opener.join()
+            if early["err"] is not None:
+                raise early["err"]
+            sc = early["sc"]
             if args.all_wells:
                 n_targets, n_slots = sc.targets_from_coords(xy[0], xy[1], None, levels=levels)
                 log("All %i wells are centres: %i neighbour slots in %i levels" % (n_targets, n_slots, levels))
@@ -480,10 +517,11 @@ def main(argv=None):
             elif err is not None:
                 raise err
         finally:
+            _lap("reports")
             if sc is not None:
                 sc.close()
     finally:
-        _lap("reports, context closed")
+        _lap("context closed")
         if out_fh:
             out_fh.close()
         if world > 1:

@@ -279,6 +279,7 @@ struct wd_ctx {
     hipEvent_t inflate_joined[kInflateStreams] = {};   // a batch's launches on a stream are done
     size_t inflate_chunk_bytes = 16u << 20;            // option "inflate_chunk_mb" (pinning memory costs time: keep the ring small)
     InflateChunk inflate_chunks[kInflateChunks];
+    std::mutex inflate_shared_mu;                      // the ring, the streams and their events are set up by one thread at a time
     size_t inflate_chunk_cap = 0;                      // bytes the chunks were allocated with
     char last_kernel[96] = "";                         // template name of the compare kernel of the last scan
     // the queue kernel's view of the targets: sorted by centre well, so that targets whose neighbourhoods
@@ -529,6 +530,7 @@ long long row_length_of(const int32_t *centre, const int32_t *lvl_off, const int
 }
 
 void drop_dense_tables(wd_ctx *ctx);
+int inflate_prepare_shared(wd_ctx *ctx, int n_chunks);
 
 // Group bases of the transposed neighbour table from host-side ring offsets (row = levels+1).
 void set_group_bases(wd_ctx *ctx, const int32_t *lvl_off, int T, int levels)
@@ -1156,6 +1158,16 @@ void wd_destroy(wd_ctx *ctx)
         return;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
+    // (WD_INFLATE_STATS: where the time to close a context goes)
+    const bool lap_on = getenv("WD_INFLATE_STATS") != nullptr;
+    auto lap_t = std::chrono::steady_clock::now();
+    auto lap = [&](const char *what) {
+        if (!lap_on)
+            return;
+        const auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "[wd close] %-28s %6.1f ms\n", what, 1e3 * std::chrono::duration<double>(now - lap_t).count());
+        lap_t = now;
+    };
     drain_events(ctx);
     for (auto &ev : ctx->free_events) {
         (void)hipEventDestroy(ev.first);
@@ -1179,6 +1191,7 @@ void wd_destroy(wd_ctx *ctx)
     (void)hipFree(ctx->d_wdelta);
     (void)hipFree(ctx->d_wlev);
     (void)hipFree(ctx->d_wmask);
+    (void)hipFree(ctx->d_wfull);
     (void)hipFree(ctx->d_tblflags);
     (void)hipFree(ctx->d_mark);
     (void)hipFree(ctx->d_sig);
@@ -1209,6 +1222,7 @@ void wd_destroy(wd_ctx *ctx)
     (void)hipFree(ctx->d_hits);
     (void)hipFree(ctx->d_gather);
     (void)hipFree(ctx->d_hit_count);
+    lap("scan buffers");
     for (auto &st : ctx->inflate_streams)
         if (st) {
             (void)hipStreamSynchronize(st);
@@ -1220,11 +1234,13 @@ void wd_destroy(wd_ctx *ctx)
     for (auto &ev : ctx->inflate_ready)
         if (ev)
             (void)hipEventDestroy(ev);
+    lap("ingest streams, events");
     for (auto &ch : ctx->inflate_chunks) {
         (void)hipHostFree(ch.pinned);
         if (ch.copied)
             (void)hipEventDestroy(ch.copied);
     }
+    lap("pinned ring");
     for (auto &sl : ctx->inflate_slots) {
         (void)hipFree(sl.arena);
         (void)hipHostFree(sl.h_jobs);
@@ -1234,6 +1250,7 @@ void wd_destroy(wd_ctx *ctx)
         if (sl.done)
             (void)hipEventDestroy(sl.done);
     }
+    lap("arenas, job tables");
     for (auto *sl : ctx->ingest_slots) {
         (void)hipHostFree(sl->pinned);
         (void)hipFree(sl->dev);
@@ -1245,6 +1262,7 @@ void wd_destroy(wd_ctx *ctx)
             (void)hipStreamDestroy(st);
     if (ctx->own_stream)
         (void)hipStreamDestroy(ctx->own_stream);
+    lap("host loader slots, streams");
     delete ctx;
 }
 
@@ -1334,6 +1352,13 @@ try {
         if (value < 1 || value > 1024)
             return WD_ERR_ARG;
         ctx->inflate_chunk_bytes = (size_t)value << 20;
+    } else if (n == "inflate_warm") {
+        // the batch loaders' pinned ring, streams and events now, not inside the first batch (callable from
+        // a thread of its own while the caller parses its targets file)
+        if (value) {
+            WD_HIP(ctx, hipSetDevice(ctx->device));
+            return inflate_prepare_shared(ctx, wd_ctx::kInflateChunks);
+        }
     } else if (n == "dense_pack") {
         ctx->dense_pack = value < 0 ? -1 : (value ? 1 : 0);
     } else if (n == "dense_windows") {
@@ -2578,10 +2603,12 @@ unsigned ring_flags()
 }
 
 // buffers of a batch: pinned ring, streams, arena for `arena_bytes` of compressed files, n job slots
-int inflate_prepare(wd_ctx *ctx, wd_ctx::InflateSlot &sl, int n_chunks, size_t arena_bytes, size_t n_jobs)
+// ... the part every batch shares: the pinned ring (pinning memory is what takes time: 25 ms for four chunks
+// of 16 MB), the streams and their events.  Also reached through option "inflate_warm", which lets a caller
+// have it done beside its own start-up work instead of inside the first batch.
+int inflate_prepare_shared(wd_ctx *ctx, int n_chunks)
 {
-    if (!sl.done && hipEventCreateWithFlags(&sl.done, hipEventDisableTiming | hipEventBlockingSync) != hipSuccess)
-        return WD_ERR_HIP;
+    std::lock_guard<std::mutex> only_one(ctx->inflate_shared_mu);         // (a warm-up call beside a batch's)
     if (ctx->inflate_chunk_cap != ctx->inflate_chunk_bytes) {            // the option changed: new buffers
         // (the batch before may still be copying out of the old ones)
         if (ctx->inflate_streams[wd_ctx::kInflateStreams] &&
@@ -2600,15 +2627,29 @@ int inflate_prepare(wd_ctx *ctx, wd_ctx::InflateSlot &sl, int n_chunks, size_t a
         if (!ch.pinned && hipHostMalloc((void **)&ch.pinned, ctx->inflate_chunk_cap + 64, ring_flags()) != hipSuccess)
             return WD_ERR_NOMEM;
     }
-    for (auto &st : ctx->inflate_streams)
-        if (!st && hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess)
+    // the copy stream and as many decode streams as are used (creating and destroying a stream costs 1 - 3 ms)
+    const int n_dec = std::max(1, std::min(wd_ctx::kInflateStreams, getenv("WD_DECODE_STREAMS") ? atoi(getenv("WD_DECODE_STREAMS"))
+                                                                                                 : ctx->inflate_decode_streams));
+    for (int u = 0; u <= wd_ctx::kInflateStreams; u++) {
+        hipStream_t &st = ctx->inflate_streams[u];
+        if ((u < n_dec || u == wd_ctx::kInflateStreams) && !st && hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess)
             return WD_ERR_HIP;
+    }
     for (auto &ev : ctx->inflate_ready)
         if (!ev && hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess)
             return WD_ERR_HIP;
     for (auto &ev : ctx->inflate_joined)
         if (!ev && hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess)
             return WD_ERR_HIP;
+    return WD_OK;
+}
+
+int inflate_prepare(wd_ctx *ctx, wd_ctx::InflateSlot &sl, int n_chunks, size_t arena_bytes, size_t n_jobs)
+{
+    if (!sl.done && hipEventCreateWithFlags(&sl.done, hipEventDisableTiming | hipEventBlockingSync) != hipSuccess)
+        return WD_ERR_HIP;
+    if (const int rc = inflate_prepare_shared(ctx, n_chunks))
+        return rc;
     if (arena_bytes > sl.arena_cap) {
         (void)hipFree(sl.arena);
         sl.arena = nullptr;
@@ -2665,6 +2706,7 @@ static int load_tile_files_batch_impl(wd_ctx *ctx, int n_files, const char *cons
         return WD_ERR_ARG;
     if (hipSetDevice(ctx->device) != hipSuccess)
         return WD_ERR_HIP;
+    const auto call_t0 = std::chrono::steady_clock::now();               // (WD_INFLATE_STATS)
     // a slot for the whole call, the shared ring / streams only while this batch is read and launched
     InflateTurn batch_lock(ctx);
     wd_ctx::InflateSlot &slot = ctx->inflate_slots[batch_lock.ticket % wd_ctx::kInflateSlots];
@@ -2684,6 +2726,7 @@ static int load_tile_files_batch_impl(wd_ctx *ctx, int n_files, const char *cons
     struct Group { int first, last; size_t bytes, arena_at; std::atomic<int> remaining{0}; };
     std::vector<std::unique_ptr<Group>> groups;
     size_t arena_bytes = 0, n_jobs = 0;
+    const auto turn_t0 = std::chrono::steady_clock::now();               // (this call's turn has come)
     // sizes, then groups of consecutive files that fit a chunk
     for (int i = 0; i < n_files; i++) {
         struct stat st;
@@ -2712,6 +2755,7 @@ static int load_tile_files_batch_impl(wd_ctx *ctx, int n_files, const char *cons
         }
     }
     const int n_groups = (int)groups.size();
+    const auto stat_t1 = std::chrono::steady_clock::now();
     if (n_groups) {
         // (interleaved layout: the planes are decoded into the arena and scattered into their byte lanes)
         const size_t plane_room = well_stride == 4 ? (((size_t)n_clusters + 8 + 255) & ~(size_t)255) : 0;
@@ -2943,10 +2987,15 @@ static int load_tile_files_batch_impl(wd_ctx *ctx, int n_files, const char *cons
         }
     ctx->inflate_files_host += n_early.load();
     ctx->inflate_files_early += n_early.load();
-    if (getenv("WD_INFLATE_STATS"))
-        fprintf(stderr, "[wd inflate] chunk loop %.1f ms for %d chunks: waited %.1f ms for the readers, %.1f ms for chunk copies\n",
-                1e3 * std::chrono::duration<double>(std::chrono::steady_clock::now() - loop_t0).count(), n_groups,
-                1e3 * wait_read_s, 1e3 * wait_copy_s);
+    if (getenv("WD_INFLATE_STATS")) {
+        auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
+            return 1e3 * std::chrono::duration<double>(b - a).count();
+        };
+        fprintf(stderr, "[wd inflate] waited %.1f ms for its turn, %.1f ms of stat, %.1f ms of buffers and the copy stream; "
+                        "chunk loop %.1f ms for %d chunks: waited %.1f ms for the readers, %.1f ms for chunk copies\n",
+                ms(call_t0, turn_t0), ms(turn_t0, stat_t1), ms(stat_t1, loop_t0),
+                ms(loop_t0, std::chrono::steady_clock::now()), n_groups, 1e3 * wait_read_s, 1e3 * wait_copy_s);
+    }
     if (dma_probe && !dma_ev.empty()) {
         (void)hipStreamSynchronize(copy_stream);
         double busy = 0, span = 0, longest = 0;
@@ -2981,12 +3030,17 @@ static int load_tile_files_batch_impl(wd_ctx *ctx, int n_files, const char *cons
     if (hip_rc != WD_OK)
         (void)hipDeviceSynchronize();                                    // nothing of a failed call stays in flight
     batch_lock.unlock();
+    const auto launched_t = std::chrono::steady_clock::now();
     if (hip_rc == WD_OK && n_groups && hipEventSynchronize(slot.done) != hipSuccess)
         hip_rc = WD_ERR_HIP;
     if (hip_rc != WD_OK)
         return hip_rc;
 
     const bool want_stats = getenv("WD_INFLATE_STATS") != nullptr;
+    if (want_stats)
+        fprintf(stderr, "[wd inflate] decoded %.1f ms after the last launch was queued, %.1f ms after the call began\n",
+                1e3 * std::chrono::duration<double>(std::chrono::steady_clock::now() - launched_t).count(),
+                1e3 * std::chrono::duration<double>(std::chrono::steady_clock::now() - call_t0).count());
     unsigned long long st[14] = {0}, real_sum = 0;
     for (size_t j = 0; j < job_file.size(); j++) {
         const int i = job_file[j];
