@@ -88,13 +88,19 @@ int wd_synchronize(wd_ctx *ctx);
  * "dense_queue_cap" (0 = 16, 32 for Levenshtein: survivor entries per 64 targets, at most 64), "dense_pack" (-1 = settle the
  * survivors on packed rows of the wells they involve whenever there are any, 0 = byte by byte on
  * the planes, 1 = rows always), "dense_windows" (1: groups of consecutive centres compare their
- * neighbours' signatures from LDS windows; 0 = every group gathers them through L1), "fast_inflate" (1:
+ * neighbours' signatures from LDS windows; 0 = every group gathers them through L1), "dense_sym" (1: when
+ * every well is a centre and the neighbour relation is symmetric - b in ring r of a exactly when a in ring
+ * r of b, every ring in ascending order: checked once per targets set - the dense path compares each pair
+ * from its lower well only and records a duplicate for both targets; 0 = every pair from both ends),
+ * "inflate_warm" (write-only: sets up the batch loaders' pinned ring, streams and events now instead of
+ * inside the first batch; may be called from a thread of its own), "fast_inflate" (1:
  * the loaders try the library's own gunzip before zlib; the environment variable WD_FAST_INFLATE
  * sets the default), "well_stride" (1 = a plane per cycle; 4 = interleaved, see wd_interleave4).
  * Read-only (wd_get_option; -1 before the first dense scan of the current targets):
  * "dense_uniform_groups" (64-target groups of consecutive centres that share their neighbour
  * offsets), "dense_window_groups" (those scanned through signature windows in LDS),
- * "dense_window_dwords" (LDS dwords per wave of the largest window).
+ * "dense_window_dwords" (LDS dwords per wave of the largest window), "dense_sym_on" (1: the tables
+ * built last are those of the one-ended compare).
  * Unknown names return WD_ERR_ARG. */
 int wd_set_option(wd_ctx *ctx, const char *name, int64_t value);
 int wd_get_option(wd_ctx *ctx, const char *name, int64_t *value);
