@@ -36,9 +36,12 @@ sc.set_option("dense_pack", a.pack)
 for ch in [int(v) for v in a.chunk.split(",")] * 2:
     sc.set_option("dense_tile_chunk", ch)
     print("dense_tile_chunk", ch, end=": ")
-    sc.profile_reset()
     sc.scan_async(tb.tables, a.tiles, a.bases, n, a.mode, a.k, out)
+    sc.profile_reset()
+    for _ in range(4):
+        sc.scan_async(tb.tables, a.tiles, a.bases, n, a.mode, a.k, out)
     ms, cnt = sc.profile_get()
+    ms /= max(1, cnt)
     blk = sc.d2h(out, a.tiles * (1 + 5 * a.levels) * 8, np.int64).reshape(a.tiles, -1)
     C = int(blk[:, 1:1 + a.levels].sum()); Tv = int(blk[:, 0].sum())
     b_dense = a.tiles * (n * a.bases + 4 * n * (1 + P / T) + n)
