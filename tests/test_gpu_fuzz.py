@@ -92,7 +92,11 @@ def test_fuzz(seed):
                         "sort_targets": int(rng.integers(0, 2)) if trial else 1,
                         "lev2_closed": int(rng.integers(0, 2)) if trial else 1,
                         "dense_overlap": int(rng.integers(0, 2)) if trial else 0,
-                        "dense_part_tiles": int(rng.choice([0, 1, 2]))}
+                        "dense_part_tiles": int(rng.choice([0, 1, 2])),
+                        # the pairs walked in the order of their neighbour wells (k_scan_lines), in blocks
+                        # of a few hundred to a few thousand pairs
+                        "line_walk": int(rng.choice([-1, 0, 1, 1])) if trial else -1,
+                        "line_pairs": int(rng.choice([0, 130, 700, 5000]))}
                 for name, v in opts.items():
                     sc.set_option(name, v)
                 try:

@@ -16,7 +16,7 @@ pytestmark = pytest.mark.gpu
 
 DEFAULT_OPTIONS = (("early_exit", 1), ("batch_first", 4), ("batch_next", 4), ("targets_per_block", 32),
                    ("queue_kernel", 1), ("queue_first", 0), ("dense_kernel", -1), ("dense_pack", -1),
-                   ("dense_queue_cap", 0), ("dense_sym", 1))
+                   ("dense_queue_cap", 0), ("dense_sym", 1), ("line_walk", -1), ("line_pairs", 0))
 
 
 @pytest.fixture(scope="module")
@@ -56,10 +56,15 @@ def test_synth_device_matches_numpy(sc):
         tb.free()
 
 
+@pytest.mark.parametrize("walk", ["targets", "lines"])
 @pytest.mark.parametrize("name", FIXTURES)
-def test_golden_fixtures(sc, name):
+def test_golden_fixtures(sc, name, walk):
     """Every golden run of the reference, reproduced on the device: per-target dup counts
-    (the reference's lane_dupl), the per-tile tally block, and the duplicate log."""
+    (the reference's lane_dupl), the per-tile tally block, and the duplicate log - target by target
+    (k_scan_q and the kernels behind it) and with the pairs walked in the order of their neighbour
+    wells (option line_walk: k_scan_lines, where it applies - equality, Hamming, Levenshtein <= 2)."""
+    sc.set_option("line_walk", 1 if walk == "lines" else 0)
+    sc.set_option("line_pairs", 700 if walk == "lines" else 0)       # (several blocks even on a fixture's few thousand pairs)
     fx = load_fixture(name)
     spec = synth.spec_from_dict(fx["spec"])
     targets, (centre, lvl_off, nbr) = fixture_targets(name)
@@ -109,8 +114,12 @@ def test_golden_fixtures(sc, name):
                 want.append((c, w, dist))
             got = sorted((int(centre[h["target"]]), int(nbr[h["slot"]]), int(h["dist"])) for h in hits)
             assert got == sorted(want)
+        if walk == "lines" and (mode != 2 or k == 2) and sc.get_option("line_walk_blocks") > 0:
+            assert sc.last_kernel().startswith("k_scan_lines"), sc.last_kernel()      # the path under test ran
     for tb in batches.values():
         tb.free()
+    sc.set_option("line_walk", -1)
+    sc.set_option("line_pairs", 0)
 
 
 # ---------------------------------------------------------------------------------------

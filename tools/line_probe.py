@@ -1,0 +1,53 @@
+#!/usr/bin/env python3
+"""The line walk (option line_walk: k_scan_lines, the pairs in the order of their neighbour wells) against
+the queue kernel (k_scan_q, target by target): same tally blocks, per-target counts and hit records, and the
+kernel times.  Usage: line_probe.py [bench|novaseq] [tiles=96]"""
+import os
+import sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np  # noqa: E402
+from well_duplicates_amd import synth, workload  # noqa: E402
+from well_duplicates_amd.scanner import Scanner, TileBatch  # noqa: E402
+
+NOVA = len(sys.argv) > 1 and sys.argv[1] == "novaseq"
+tiles = int(sys.argv[2]) if len(sys.argv) > 2 else 96
+sc = Scanner(0)
+sc.set_option("line_pairs", int(os.environ.get("WD_LINE_PAIRS", "0")))
+if NOVA:
+    from well_duplicates_amd import cluster_indexes
+    rows, cols = workload.NOVASEQ_ROWS, workload.NOVASEQ_COLS
+    x, y = synth.honeycomb_pixels(rows, cols)
+    sc.targets_from_coords(x, y, cluster_indexes.sample_centres(rows * cols, 10000, 13), levels=7,
+                           max_dists=cluster_indexes.max_dists_for(7))
+else:
+    rows, cols = workload.HISEQ4000_ROWS, workload.HISEQ4000_COLS
+    centre, lvl_off, nbr = workload.honeycomb_targets(rows, cols, 2500, 5, seed=13)
+    sc.set_targets(centre, lvl_off, nbr)
+n = rows * cols
+tb = TileBatch(sc, tiles, 50, n)
+tb.fill_synthetic(synth.SynthSpec(seed=2 if not NOVA else 4, n_clusters=n, row=cols, plant_per_64k=1311),
+                  [(1, int(t)) for t in workload.tiles_for_stype(workload.NOVASEQ_STYPE if NOVA else "hiseq_x")[:tiles]],
+                  list(range(50)))
+cap = 4000000
+for mode, k, name in ((0, 0, "equality"), (1, 1, "hamming<=1"), (1, 2, "hamming<=2"), (2, 2, "lev<=2")):
+    ref = None
+    for lw in (0, 1, 1):
+        sc.set_option("line_walk", lw)
+        sc.hitlog_enable(cap)
+        blocks, pt = tb.count(mode, k, per_target=True)
+        hits, total = sc.hitlog_fetch(cap)
+        sc.hitlog_enable(0)
+        hl = np.sort(hits, order=["tile", "target", "slot"])
+        if ref is None:
+            ref = (blocks, pt, hl, total)
+        same = bool((blocks == ref[0]).all() and (pt == ref[1]).all() and total == ref[3] and (hl == ref[2]).all())
+        sc.set_option("profile", 1)
+        sc.profile_reset()
+        for _ in range(10):
+            tb.count(mode, k)
+        ms, cnt = sc.profile_get()
+        sc.set_option("profile", 0)
+        print("%-12s line_walk %d: %.4f ms  same counters, per-target counts and %d hit records %s  [%s] blocks %d"
+              % (name, lw, ms / max(1, cnt), total, same, sc.last_kernel(), sc.get_option("line_walk_blocks")), flush=True)
+sc.set_option("line_walk", 0)
+sc.close()

@@ -69,6 +69,7 @@ constexpr uint32_t kStatusEmptyLevel = 1u;
 #include "scan_sequential.inc"
 #include "lev2_stream.inc"
 #include "scan_queue.inc"
+#include "scan_lines.inc"
 #include "scan_dense.inc"
 #include "scan_lev_generic.inc"
 #include "gen_rings.inc"
@@ -285,6 +286,15 @@ struct wd_ctx {
     // the queue kernel's view of the targets: sorted by centre well, so that targets whose neighbourhoods
     // share cache lines sit in the same workgroup (install_sorted_view); null = the file's order is sorted
     int32_t *d_centre_q = nullptr, *d_lvl_off_q = nullptr, *d_perm = nullptr;
+    // the line walk's view (build_line_tables, scan_lines.inc): the (target, slot) pairs sorted by neighbour well
+    int line_walk = -1;                                // option: 1 = k_scan_lines where it applies, 0 = never, -1 = where the
+                                                       // targets are dense enough for it to pay (line_walk_wanted)
+    int32_t *d_lw_well = nullptr;
+    uint32_t *d_lw_meta = nullptr, *d_lw_btgt = nullptr;
+    int4 *d_lw_blk = nullptr;
+    int lw_blocks = -1;                                // -1: not built for the current targets; 0: does not apply to them
+    int lw_tmax = 0;                                   // most targets of any block
+    int line_pairs = 0;                                // option: pairs per block of the line walk (0 = kLwPairs)
     int sort_targets = 1;                              // option: use it (0: file order, as rounds 1 and 2)
     int sort_strip = 256;                              // option: width of the column strips of that order (0: plain well order)
     int lev2_closed = 1;                               // option: Levenshtein <= 2 by the closed form (0: banded DP)
@@ -530,6 +540,7 @@ long long row_length_of(const int32_t *centre, const int32_t *lvl_off, const int
 }
 
 void drop_dense_tables(wd_ctx *ctx);
+void drop_line_tables(wd_ctx *ctx);
 int inflate_prepare_shared(wd_ctx *ctx, int n_chunks);
 
 // Group bases of the transposed neighbour table from host-side ring offsets (row = levels+1).
@@ -553,6 +564,7 @@ void set_group_bases(wd_ctx *ctx, const int32_t *lvl_off, int T, int levels)
 // The dense path's device tables are built on its first scan after this (ensure_dense_tables).
 void drop_dense_tables(wd_ctx *ctx)
 {
+    drop_line_tables(ctx);                             // (new targets - or an option of the dense tables: rebuilt on demand)
     (void)hipFree(ctx->d_nbr_t);
     (void)hipFree(ctx->d_gbase);
     (void)hipFree(ctx->d_rel_t);
@@ -1061,6 +1073,179 @@ int launch_dense(wd_ctx *ctx, const ScanArgs &a, int n_tiles, int64_t N, bool st
     return WD_OK;
 }
 
+// Automatic choice (option line_walk = -1): the line walk pays where the targets' neighbourhoods overlap
+// - measured on MI355X: 0.40 pairs per well (BASELINE configs[3]: 10 000 targets x 163 neighbours on 4.09 M
+// wells) Levenshtein <= 2 1.43 -> 0.99 ms, Hamming <= 2 1.30 -> 0.87, equality 0.57 -> 0.51; 0.05 pairs per
+// well (the bench workload) 4 - 10 % slower than the queue kernel, whose walk is target by target.
+bool line_walk_wanted(const wd_ctx *ctx)
+{
+    if (ctx->line_walk >= 0)
+        return ctx->line_walk != 0;
+    const double span = (double)(ctx->idx_max - ctx->idx_min + 1);
+    return ctx->T >= 512 && ctx->P >= (1 << 16) && ctx->P <= (1ll << 24) && span > 0 && (double)ctx->P >= 0.15 * span;
+}
+
+void drop_line_tables(wd_ctx *ctx)
+{
+    (void)hipFree(ctx->d_lw_well);
+    (void)hipFree(ctx->d_lw_meta);
+    (void)hipFree(ctx->d_lw_btgt);
+    (void)hipFree(ctx->d_lw_blk);
+    ctx->d_lw_well = nullptr;
+    ctx->d_lw_meta = ctx->d_lw_btgt = nullptr;
+    ctx->d_lw_blk = nullptr;
+    ctx->lw_blocks = -1;
+}
+
+// The line walk's tables (scan_lines.inc), built on the first scan that wants them: every (target, slot)
+// pair of the current targets, sorted by neighbour well, cut into blocks of at most kLwPairs pairs that
+// involve at most kLwTargets targets.  lw_blocks = 0 if the walk does not apply (an empty ring, more than
+// 4095 slots in a target, no pairs, too many of them).
+int build_line_tables(wd_ctx *ctx)
+{
+    if (ctx->lw_blocks >= 0)
+        return WD_OK;
+    ctx->lw_blocks = 0;
+    const int T = ctx->T, levels = ctx->levels;
+    const int64_t P = ctx->P;
+    if (T < 1 || levels < 1 || P < 1 || P > (1ll << 26) || ctx->has_empty_level || ctx->k_max > 4095)
+        return WD_OK;
+    const size_t row = (size_t)levels + 1;
+    std::vector<int32_t> off((size_t)T * row), nbr((size_t)P);
+    WD_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    WD_HIP(ctx, hipMemcpy(off.data(), ctx->d_lvl_off, off.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
+    WD_HIP(ctx, hipMemcpy(nbr.data(), ctx->d_nbr, nbr.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
+    // (well, target, slot) of every pair; a target's slots are [off[t][0], off[t][levels]) of nbr
+    struct Pair { int32_t well, t; uint32_t slot; };
+    std::vector<Pair> pairs;
+    pairs.reserve((size_t)P);
+    for (int t = 0; t < T; t++) {
+        const int32_t b = off[(size_t)t * row], e = off[(size_t)t * row + levels];
+        if (b < 0 || e > P || e < b)
+            return WD_OK;
+        for (int32_t i = b; i < e; i++)
+            pairs.push_back(Pair{nbr[(size_t)i], t, (uint32_t)(i - b)});
+    }
+    if (pairs.empty())
+        return WD_OK;
+    {
+        // by well, stable (equal wells stay in target order): three counting passes of 11 bits - a comparison
+        // sort of a few million pairs would be a tenth of a second of every run's start-up
+        std::vector<Pair> tmp(pairs.size());
+        int32_t lo_well = pairs[0].well;
+        for (const Pair &q : pairs)
+            lo_well = std::min(lo_well, q.well);
+        for (int pass = 0; pass < 3; pass++) {
+            std::vector<size_t> cnt(2049, 0);
+            const int sh = 11 * pass;
+            auto digit = [&](const Pair &q) { return (size_t)(((uint32_t)(q.well - lo_well) >> sh) & 2047u); };
+            for (const Pair &q : pairs)
+                cnt[digit(q) + 1]++;
+            for (int d = 0; d < 2048; d++)
+                cnt[(size_t)d + 1] += cnt[(size_t)d];
+            for (const Pair &q : pairs)
+                tmp[cnt[digit(q)]++] = q;
+            pairs.swap(tmp);
+        }
+        // (33 bits of spread would need a fourth pass: wells are int32 and tiles hold a few million)
+        if ((uint32_t)(pairs.back().well - lo_well) >> 31)
+            return WD_OK;
+        for (size_t i = 1; i < pairs.size(); i++)
+            if (pairs[i - 1].well > pairs[i].well) {                 // (spread above 2^33 cannot happen; belt and braces)
+                std::stable_sort(pairs.begin(), pairs.end(), [](const Pair &x, const Pair &y) { return x.well < y.well; });
+                break;
+            }
+    }
+    const size_t n = pairs.size();
+    std::vector<int32_t> well(n);
+    std::vector<uint32_t> meta(n), btgt;
+    std::vector<int4> blk;
+    std::vector<int> local((size_t)T, -1), seen_in((size_t)T, -1);
+    std::vector<char> counted((size_t)T, 0);
+    size_t first = 0;
+    const size_t per_block = (size_t)(ctx->line_pairs > 0 ? ctx->line_pairs : kLwPairs);
+    int tmax = 0;
+    while (first < n) {
+        const int b = (int)blk.size();
+        const size_t tgt0 = btgt.size();
+        size_t i = first;
+        for (; i < n && i - first < per_block; i++) {
+            const int t = pairs[i].t;
+            if (seen_in[(size_t)t] != b) {
+                if (btgt.size() - tgt0 == (size_t)kLwTargets)
+                    break;                                       // the block's target table is full
+                seen_in[(size_t)t] = b;
+                local[(size_t)t] = (int)(btgt.size() - tgt0);
+                btgt.push_back((uint32_t)t | (counted[(size_t)t] ? 0u : 0x80000000u));   // the first block to see it owns it
+                counted[(size_t)t] = 1;
+            }
+            well[i] = pairs[i].well;
+            meta[i] = ((uint32_t)local[(size_t)t] << 16) | pairs[i].slot;
+        }
+        blk.push_back(make_int4((int)first, (int)(i - first), (int)tgt0, (int)(btgt.size() - tgt0)));
+        tmax = std::max(tmax, (int)(btgt.size() - tgt0));
+        first = i;
+    }
+    ctx->lw_tmax = (tmax + 3) & ~3;
+    // (a target without a single pair would never be counted: has_empty_level excludes it)
+    WD_HIP(ctx, hipMalloc((void **)&ctx->d_lw_well, n * sizeof(int32_t)));
+    WD_HIP(ctx, hipMalloc((void **)&ctx->d_lw_meta, n * sizeof(uint32_t)));
+    WD_HIP(ctx, hipMalloc((void **)&ctx->d_lw_btgt, btgt.size() * sizeof(uint32_t)));
+    WD_HIP(ctx, hipMalloc((void **)&ctx->d_lw_blk, blk.size() * sizeof(int4)));
+    WD_HIP(ctx, hipMemcpy(ctx->d_lw_well, well.data(), n * sizeof(int32_t), hipMemcpyHostToDevice));
+    WD_HIP(ctx, hipMemcpy(ctx->d_lw_meta, meta.data(), n * sizeof(uint32_t), hipMemcpyHostToDevice));
+    WD_HIP(ctx, hipMemcpy(ctx->d_lw_btgt, btgt.data(), btgt.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    WD_HIP(ctx, hipMemcpy(ctx->d_lw_blk, blk.data(), blk.size() * sizeof(int4), hipMemcpyHostToDevice));
+    ctx->lw_blocks = (int)blk.size();
+    return WD_OK;
+}
+
+// k_scan_lines for equality / Hamming <= k (first round of `first` cycles) or Levenshtein <= 2 (closed form)
+template <bool STRIDED>
+int launch_lines(wd_ctx *ctx, const ScanArgs &sa, int n_tiles, bool lev2, int first)
+{
+    LineArgs a;
+    a.s = sa;
+    a.s.perm = nullptr;
+    a.pw = ctx->d_lw_well;
+    a.pm = ctx->d_lw_meta;
+    a.blk = ctx->d_lw_blk;
+    a.btgt = ctx->d_lw_btgt;
+    a.n_blk = ctx->lw_blocks;
+    a.tmax = ctx->lw_tmax;
+    a.mask_stride = (((long long)sa.T + 3) / 4 + 31) & ~31ll;
+    if (int rc = dense_reserve(ctx, ctx->d_mask, ctx->mask_cap, (size_t)n_tiles * (size_t)a.mask_stride, "hit masks"))
+        return rc;
+    a.mask = ctx->d_mask;
+    WD_HIP(ctx, hipMemsetAsync(a.mask, 0, (size_t)n_tiles * (size_t)a.mask_stride * sizeof(uint32_t), ctx->stream));
+    if (sa.out_per_target)
+        WD_HIP(ctx, hipMemsetAsync(sa.out_per_target, 0, (size_t)n_tiles * sa.T * sa.levels * sizeof(uint32_t), ctx->stream));
+    const long long nblocks = (long long)ctx->lw_blocks * n_tiles;
+    if (nblocks > 0x7FFFFFFFll)
+        return fail(ctx, WD_ERR_UNSUPPORTED, "grid too large");
+    const dim3 grid((unsigned)nblocks);
+    const size_t lds = (size_t)scan_lines_lds_dwords(sa.levels, ctx->lw_tmax) * sizeof(uint32_t);
+#define WD_LAUNCH_L(B1_, LEVH_)                                                                          \
+    do {                                                                                                 \
+        snprintf(ctx->last_kernel, sizeof(ctx->last_kernel), "k_scan_lines<%s, %d, %d>", STRIDED ? "true" : "false", \
+                 (int)(B1_), (int)(LEVH_));                                                              \
+        hipLaunchKernelGGL((k_scan_lines<STRIDED, (B1_), (LEVH_)>), grid, dim3(kBlock), lds, ctx->stream, a); \
+    } while (0)
+    if (lev2) {
+        WD_LAUNCH_L(5, kLev2Closed);
+    } else {
+        switch (first) {
+        case 2: WD_LAUNCH_L(2, 0); break;
+        case 3: WD_LAUNCH_L(3, 0); break;
+        case 5: WD_LAUNCH_L(5, 0); break;
+        case 6: WD_LAUNCH_L(6, 0); break;
+        default: WD_LAUNCH_L(8, 0); break;
+        }
+    }
+#undef WD_LAUNCH_L
+    return WD_OK;
+}
+
 bool valid_batches(int b1, int b2)
 {
     for (auto &p : kHamShapes)
@@ -1204,6 +1389,7 @@ void wd_destroy(wd_ctx *ctx)
     (void)hipFree(ctx->d_centre_q);
     (void)hipFree(ctx->d_lvl_off_q);
     (void)hipFree(ctx->d_perm);
+    drop_line_tables(ctx);
     for (hipStream_t q : {ctx->dense_hi, ctx->dense_lo})
         if (q) {
             (void)hipStreamSynchronize(q);
@@ -1334,6 +1520,16 @@ try {
         if (value < 0 || value > 65535)
             return WD_ERR_ARG;
         ctx->dense_part_tiles = (int)value;
+    } else if (n == "line_walk") {
+        ctx->line_walk = value < 0 ? -1 : (value ? 1 : 0);
+    } else if (n == "line_pairs") {
+        if (value < 0 || value > (1 << 20))
+            return WD_ERR_ARG;
+        if (value != ctx->line_pairs) {
+            WD_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            drop_line_tables(ctx);
+        }
+        ctx->line_pairs = (int)value;
     } else if (n == "sort_targets") {
         ctx->sort_targets = value ? 1 : 0;
     } else if (n == "sort_strip") {
@@ -1412,6 +1608,9 @@ try {
     else if (n == "test_thread_limit") *value = ctx->test_thread_limit;
     else if (n == "lev2_closed") *value = ctx->lev2_closed;
     else if (n == "sort_targets") *value = ctx->sort_targets;
+    else if (n == "line_walk") *value = ctx->line_walk;
+    else if (n == "line_pairs") *value = ctx->line_pairs;
+    else if (n == "line_walk_blocks") *value = ctx->lw_blocks;      // read-only: blocks of the line walk's tables (-1: not built, 0: does not apply)
     else if (n == "sort_strip") *value = ctx->sort_strip;
     else if (n == "dense_overlap") *value = ctx->dense_overlap;
     else if (n == "dense_part_tiles") *value = ctx->dense_part_tiles;
@@ -1724,6 +1923,16 @@ try {
         return fail(ctx, WD_ERR_UNSUPPORTED,
                     "the interleaved layout is read by the queue kernel only (equality, Hamming, Levenshtein <= 3)");
 
+    // the line walk (scan_lines.inc): the pairs in the order of their neighbour wells, where the queue kernel
+    // would run (planes, early exit, equality / Hamming, or Levenshtein <= 2 by the closed form)
+    bool use_lines = false;
+    if (line_walk_wanted(ctx) && !use_dense && ws == 1 && ctx->queue_kernel && ctx->early_exit && L >= 1 && levels <= 8 &&
+        (use_queue || (lev && kk == 2 && ctx->lev2_closed && !lev_generic))) {
+        if (int rc = build_line_tables(ctx))
+            return rc;
+        use_lines = ctx->lw_blocks > 0;
+    }
+
     std::pair<hipEvent_t, hipEvent_t> ev{nullptr, nullptr};
     const bool timed = ctx->profile > 0 && (ctx->profile_seq++ % ctx->profile) == 0;
     if (timed) {
@@ -1743,6 +1952,11 @@ try {
         snprintf(ctx->last_kernel, sizeof(ctx->last_kernel), "dense chain v%d, %s%s (k_dense_sig .. k_dense_reduce)",
                  kDenseChainVersion, lev2 ? "Levenshtein <= 2" : (kk > 0 ? "Hamming" : "equality"),
                  ctx->dense_sym_on ? ", pairs from one end" : "");
+    } else if (use_lines) {
+        const int first = kk <= 0 ? 2 : (kk == 1 ? 3 : (kk == 2 ? 5 : (kk == 3 ? 6 : 8)));
+        const int rc = strided ? launch_lines<true>(ctx, a, n_tiles, lev, first) : launch_lines<false>(ctx, a, n_tiles, lev, first);
+        if (rc)
+            return rc;
     } else if (use_queue) {
         queue_view(ctx, a);
         if (strided)
