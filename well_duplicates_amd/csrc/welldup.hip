@@ -292,6 +292,7 @@ struct wd_ctx {
     int32_t *d_lw_well = nullptr;
     uint32_t *d_lw_meta = nullptr, *d_lw_btgt = nullptr;
     int4 *d_lw_blk = nullptr;
+    int32_t *d_lw_bcen = nullptr;
     int lw_blocks = -1;                                // -1: not built for the current targets; 0: does not apply to them
     int lw_tmax = 0;                                   // most targets of any block
     int line_pairs = 0;                                // option: pairs per block of the line walk (0 = kLwPairs)
@@ -1091,6 +1092,8 @@ void drop_line_tables(wd_ctx *ctx)
     (void)hipFree(ctx->d_lw_meta);
     (void)hipFree(ctx->d_lw_btgt);
     (void)hipFree(ctx->d_lw_blk);
+    (void)hipFree(ctx->d_lw_bcen);
+    ctx->d_lw_bcen = nullptr;
     ctx->d_lw_well = nullptr;
     ctx->d_lw_meta = ctx->d_lw_btgt = nullptr;
     ctx->d_lw_blk = nullptr;
@@ -1111,8 +1114,9 @@ int build_line_tables(wd_ctx *ctx)
     if (T < 1 || levels < 1 || P < 1 || P > (1ll << 26) || ctx->has_empty_level || ctx->k_max > 4095)
         return WD_OK;
     const size_t row = (size_t)levels + 1;
-    std::vector<int32_t> off((size_t)T * row), nbr((size_t)P);
+    std::vector<int32_t> off((size_t)T * row), nbr((size_t)P), cen((size_t)T);
     WD_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    WD_HIP(ctx, hipMemcpy(cen.data(), ctx->d_centre, cen.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
     WD_HIP(ctx, hipMemcpy(off.data(), ctx->d_lvl_off, off.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
     WD_HIP(ctx, hipMemcpy(nbr.data(), ctx->d_nbr, nbr.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
     // (well, target, slot) of every pair; a target's slots are [off[t][0], off[t][levels]) of nbr
@@ -1192,6 +1196,11 @@ int build_line_tables(wd_ctx *ctx)
     WD_HIP(ctx, hipMalloc((void **)&ctx->d_lw_meta, n * sizeof(uint32_t)));
     WD_HIP(ctx, hipMalloc((void **)&ctx->d_lw_btgt, btgt.size() * sizeof(uint32_t)));
     WD_HIP(ctx, hipMalloc((void **)&ctx->d_lw_blk, blk.size() * sizeof(int4)));
+    std::vector<int32_t> bcen(btgt.size());
+    for (size_t i = 0; i < btgt.size(); i++)
+        bcen[i] = cen[(size_t)(btgt[i] & 0x7FFFFFFFu)];
+    WD_HIP(ctx, hipMalloc((void **)&ctx->d_lw_bcen, bcen.size() * sizeof(int32_t)));
+    WD_HIP(ctx, hipMemcpy(ctx->d_lw_bcen, bcen.data(), bcen.size() * sizeof(int32_t), hipMemcpyHostToDevice));
     WD_HIP(ctx, hipMemcpy(ctx->d_lw_well, well.data(), n * sizeof(int32_t), hipMemcpyHostToDevice));
     WD_HIP(ctx, hipMemcpy(ctx->d_lw_meta, meta.data(), n * sizeof(uint32_t), hipMemcpyHostToDevice));
     WD_HIP(ctx, hipMemcpy(ctx->d_lw_btgt, btgt.data(), btgt.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
@@ -1211,6 +1220,7 @@ int launch_lines(wd_ctx *ctx, const ScanArgs &sa, int n_tiles, bool lev2, int fi
     a.pm = ctx->d_lw_meta;
     a.blk = ctx->d_lw_blk;
     a.btgt = ctx->d_lw_btgt;
+    a.bcen = ctx->d_lw_bcen;
     a.n_blk = ctx->lw_blocks;
     a.tmax = ctx->lw_tmax;
     a.mask_stride = (((long long)sa.T + 3) / 4 + 31) & ~31ll;
