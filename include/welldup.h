@@ -92,6 +92,11 @@ int wd_synchronize(wd_ctx *ctx);
  * every well is a centre and the neighbour relation is symmetric - b in ring r of a exactly when a in ring
  * r of b, every ring in ascending order: checked once per targets set - the dense path compares each pair
  * from its lower well only and records a duplicate for both targets; 0 = every pair from both ends),
+ * "line_walk" (-1: sampled targets dense enough for it - at least 0.15 (target, slot) pairs per well of the
+ * span of the indices - are scanned pair by pair in the order of the neighbour wells, so that a cache line
+ * is fetched once per cycle however many targets want it; 1 = wherever it applies (equality, Hamming,
+ * Levenshtein <= 2 on plane-per-cycle input), 0 = never), "line_pairs" (0 = 12288: pairs per workgroup of
+ * that walk),
  * "inflate_warm" (write-only: sets up the batch loaders' pinned ring, streams and events now instead of
  * inside the first batch; may be called from a thread of its own), "fast_inflate" (1:
  * the loaders try the library's own gunzip before zlib; the environment variable WD_FAST_INFLATE
@@ -100,7 +105,8 @@ int wd_synchronize(wd_ctx *ctx);
  * "dense_uniform_groups" (64-target groups of consecutive centres that share their neighbour
  * offsets), "dense_window_groups" (those scanned through signature windows in LDS),
  * "dense_window_dwords" (LDS dwords per wave of the largest window), "dense_sym_on" (1: the tables
- * built last are those of the one-ended compare).
+ * built last are those of the one-ended compare), "line_walk_blocks" (workgroups per tile of the line
+ * walk's tables: -1 not built, 0 = the walk does not apply to these targets).
  * Unknown names return WD_ERR_ARG. */
 int wd_set_option(wd_ctx *ctx, const char *name, int64_t value);
 int wd_get_option(wd_ctx *ctx, const char *name, int64_t *value);
