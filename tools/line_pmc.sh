@@ -1,7 +1,7 @@
 cd /tmp && export TMPDIR=/tmp; R=$GRAFT_REPO_ROOT
 for pass in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY" "FETCH_SIZE TCC_EA0_RDREQ_sum" "TCC_HIT_sum TCC_MISS_sum"; do
   d=/tmp/lwp_$(echo $pass | cut -c1-6 | tr -d ' '); rm -rf $d
-  WD_LINE_PAIRS=12288 rocprofv3 --pmc $pass --kernel-trace -d $d -o run --output-format csv -- python3 $R/tools/line_probe.py novaseq 96 > /dev/null 2>&1
+  WD_LINE_PAIRS=12288 rocprofv3 --pmc $pass --kernel-trace -d $d -o run --output-format csv -- python3 $R/tools/line_probe.py ${WD_LINE_WORKLOAD:-novaseq} 96 > /dev/null 2>&1
   python3 - $d <<'PY'
 import csv, glob, sys, collections
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
