@@ -29,6 +29,15 @@ tb.fill_synthetic(synth.SynthSpec(seed=2 if not NOVA else 4, n_clusters=n, row=c
                   [(1, int(t)) for t in workload.tiles_for_stype(workload.NOVASEQ_STYPE if NOVA else "hiseq_x")[:tiles]],
                   list(range(50)))
 cap = 4000000
+import time  # noqa: E402
+sc.set_option("line_walk", 1)
+t0 = time.perf_counter()
+tb.count(0, 0)
+t1 = time.perf_counter()
+tb.count(0, 0)
+t2 = time.perf_counter()
+print("line tables: %.1f ms to build (first scan %.1f ms, second %.1f ms), %d blocks"
+      % ((t1 - t0 - (t2 - t1)) * 1e3, (t1 - t0) * 1e3, (t2 - t1) * 1e3, sc.get_option("line_walk_blocks")), flush=True)
 for mode, k, name in ((0, 0, "equality"), (1, 1, "hamming<=1"), (1, 2, "hamming<=2"), (2, 2, "lev<=2")):
     ref = None
     for lw in (0, 1, 1):
