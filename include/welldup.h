@@ -92,9 +92,9 @@ int wd_synchronize(wd_ctx *ctx);
  * every well is a centre and the neighbour relation is symmetric - b in ring r of a exactly when a in ring
  * r of b, every ring in ascending order: checked once per targets set - the dense path compares each pair
  * from its lower well only and records a duplicate for both targets; 0 = every pair from both ends),
- * "line_walk" (-1: sampled targets dense enough for it - at least 0.15 (target, slot) pairs per well of the
- * span of the indices - are scanned pair by pair in the order of the neighbour wells, so that a cache line
- * is fetched once per cycle however many targets want it; 1 = wherever it applies (equality, Hamming,
+ * "line_walk" (-1: sampled targets of more than 127 neighbour slots on average are scanned pair by pair in
+ * the order of the neighbour wells, so that a cache line is fetched once per cycle however many targets
+ * want it; 1 = wherever it applies (equality, Hamming,
  * Levenshtein <= 2 on plane-per-cycle input), 0 = never), "line_pairs" (0 = 12288: pairs per workgroup of
  * that walk),
  * "inflate_warm" (write-only: sets up the batch loaders' pinned ring, streams and events now instead of

@@ -21,8 +21,18 @@ if NOVA:
                            max_dists=cluster_indexes.max_dists_for(7))
 else:
     rows, cols = workload.HISEQ4000_ROWS, workload.HISEQ4000_COLS
-    centre, lvl_off, nbr = workload.honeycomb_targets(rows, cols, 2500, 5, seed=13)
-    sc.set_targets(centre, lvl_off, nbr)
+    n_targets, n_levels = int(os.environ.get("WD_LINE_TARGETS", "2500")), int(os.environ.get("WD_LINE_LEVELS", "5"))
+    if n_levels <= 5:
+        centre, lvl_off, nbr = workload.honeycomb_targets(rows, cols, n_targets, n_levels, seed=13)
+        sc.set_targets(centre, lvl_off, nbr)
+    else:
+        from well_duplicates_amd import cluster_indexes
+        x, y = synth.honeycomb_pixels(rows, cols)
+        sc.targets_from_coords(x, y, cluster_indexes.sample_centres(rows * cols, n_targets, 13), levels=n_levels,
+                               max_dists=cluster_indexes.max_dists_for(n_levels))
+    _c, _o, _n = sc.get_targets()
+    T, levels, P = _c.shape[0], _o.shape[1] - 1, _n.shape[0]
+    print("%d targets x %d levels: %d pairs, %.3f per well" % (T, levels, P, P / (rows * cols)), flush=True)
 n = rows * cols
 tb = TileBatch(sc, tiles, 50, n)
 tb.fill_synthetic(synth.SynthSpec(seed=2 if not NOVA else 4, n_clusters=n, row=cols, plant_per_64k=1311),
@@ -38,7 +48,10 @@ tb.count(0, 0)
 t2 = time.perf_counter()
 print("line tables: %.1f ms to build (first scan %.1f ms, second %.1f ms), %d blocks"
       % ((t1 - t0 - (t2 - t1)) * 1e3, (t1 - t0) * 1e3, (t2 - t1) * 1e3, sc.get_option("line_walk_blocks")), flush=True)
-for mode, k, name in ((0, 0, "equality"), (1, 1, "hamming<=1"), (1, 2, "hamming<=2"), (2, 2, "lev<=2")):
+MODES = ((0, 0, "equality"), (1, 1, "hamming<=1"), (1, 2, "hamming<=2"), (2, 2, "lev<=2"))
+if os.environ.get("WD_LINE_MODES"):
+    MODES = [m for m in MODES if m[2] in os.environ["WD_LINE_MODES"].split(",")]
+for mode, k, name in MODES:
     ref = None
     for lw in (0, 1, 1):
         sc.set_option("line_walk", lw)

@@ -1074,16 +1074,21 @@ int launch_dense(wd_ctx *ctx, const ScanArgs &a, int n_tiles, int64_t N, bool st
     return WD_OK;
 }
 
-// Automatic choice (option line_walk = -1): the line walk pays where the targets' neighbourhoods overlap
-// - measured on MI355X: 0.40 pairs per well (BASELINE configs[3]: 10 000 targets x 163 neighbours on 4.09 M
-// wells) Levenshtein <= 2 1.43 -> 0.99 ms, Hamming <= 2 1.30 -> 0.87, equality 0.57 -> 0.51; 0.05 pairs per
-// well (the bench workload) 4 - 10 % slower than the queue kernel, whose walk is target by target.
+// Automatic choice (option line_walk = -1).  Measured on MI355X (tools/line_probe.py, 96 tiles, k_scan_q ->
+// k_scan_lines, equality / Levenshtein <= 2):
+//     7 rings, 163 slots per target:  2 500 targets 0.191 -> 0.188 / 0.515 -> 0.390 ms;  5 000: 0.348 -> 0.314 /
+//                                     0.895 -> 0.617;  10 000 (BASELINE configs[3]): 0.57 -> 0.50 / 1.43 -> 0.99
+//     5 rings,  86 slots per target:  2 500 targets (the bench workload) 0.124 -> 0.136 / 0.262 -> 0.277;  5 000:
+//                                     0.208 -> 0.239 / 0.442 -> 0.483;  20 000: 0.606 -> 0.623 / 1.241 -> 1.207
+// It is the size of the neighbourhoods that decides, not how densely the targets lie: the queue kernel pays
+// per (target, pass of 127 slots) - a target of 163 slots is two passes, the second a quarter full - the line
+// walk per pair, plus a prologue per (target, block) that 86 pairs do not amortise.  Hence: the line walk for
+// targets of more than one pass on average.
 bool line_walk_wanted(const wd_ctx *ctx)
 {
     if (ctx->line_walk >= 0)
         return ctx->line_walk != 0;
-    const double span = (double)(ctx->idx_max - ctx->idx_min + 1);
-    return ctx->T >= 512 && ctx->P >= (1 << 16) && ctx->P <= (1ll << 24) && span > 0 && (double)ctx->P >= 0.15 * span;
+    return ctx->T >= 512 && ctx->P >= (1 << 16) && ctx->P <= (1ll << 24) && ctx->P > (int64_t)kPass * ctx->T;
 }
 
 void drop_line_tables(wd_ctx *ctx)
