@@ -15,6 +15,7 @@ n = rows * cols
 centre, lvl_off, nbr = workload.honeycomb_targets(rows, cols, 2500, 5, seed=13)
 L = 50
 sc = Scanner(0)
+sc.set_option("line_walk", int(os.environ.get("WD_LINE_WALK", "-1")))      # 1: the pairs in the order of their neighbour wells
 sc.set_targets(centre, lvl_off, nbr)
 for label, kw in (("ordinary reads", dict()), ("every read equal (all no-calls)", dict(nocall_per_64k=65536))):
     spec = synth.SynthSpec(seed=2, n_clusters=n, row=cols, **kw)
@@ -32,8 +33,8 @@ for label, kw in (("ordinary reads", dict()), ("every read equal (all no-calls)"
             sc.set_option("profile", 0)
             dups = int(np.asarray(blocks)[:, 6:11].sum())
             wells = int(np.asarray(blocks)[:, 1:6].sum())
-            print("%-52s %-12s %-15s %8.3f ms per %d tiles = %7.2f us/tile, dups/compares %.3f"
+            print("%-52s %-12s %-15s %8.3f ms per %d tiles = %7.2f us/tile, dups/compares %.3f  [%s]"
                   % (label, "interleaved" if interleave == 4 else "planes", name, ms / cnt, tiles, ms / cnt / tiles * 1e3,
-                     dups / max(1, wells)), flush=True)
+                     dups / max(1, wells), sc.last_kernel()), flush=True)
         sc.set_option("well_stride", 1)
         tb.free()
