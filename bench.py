@@ -833,6 +833,25 @@ def main(argv=None):
             torch.cuda.synchronize()
             low["all_duplicates"] = bool((scratch.cpu().numpy()[:, 1 + levels:1 + 2 * levels]
                                           == scratch.cpu().numpy()[:, 1:1 + levels]).all())
+            # ... and on a whole lane, as the headline is (8 tiles do not fill the chip), beside the time the
+            # same loads take when nothing is left out on ordinary reads (the full gather: every neighbour's
+            # every cycle is what the worst case has to read too)
+            if args.tiles > n_ld:
+                ld = TileBatch(sc, args.tiles, L, n_clusters)
+                ld.fill_synthetic(flat, lane_tile[:args.tiles], list(range(L)))
+                big = torch.zeros((args.tiles, ncnt), dtype=torch.int64, device="cuda")
+                for name, m2, k2 in (("equality", MODE_EQ, 0), ("levenshtein_k2", MODE_LEVENSHTEIN, 2)):
+                    sc.scan_async(ld.tables, args.tiles, L, n_clusters, m2, k2, big.data_ptr())
+                    sc.profile_reset()
+                    for _ in range(3):
+                        sc.scan_async(ld.tables, args.tiles, L, n_clusters, m2, k2, big.data_ptr())
+                    w_ms2, w_n2 = sc.profile_get()
+                    low["lane_planes_%s_us_per_tile" % name] = round(w_ms2 / max(1, w_n2) / args.tiles * 1e3, 2)
+                sc.scan_status()
+                torch.cuda.synchronize()
+                ld.free()
+                low["lane_tiles"] = args.tiles
+                low["lane_full_gather_on_ordinary_reads_us_per_tile"] = None if worst is None else round(worst / args.tiles * 1e3, 2)
             other["low_diversity_worst_case"] = low
     sc.set_option("profile", 0)
     # BASELINE configs[4] in small: every well of a tile is a centre (device-generated rings,
