@@ -430,6 +430,76 @@ def test_errors_and_edges(sc):
     tb.free()
 
 
+def test_line_walk_limits(sc):
+    """Where the line walk (option line_walk, csrc/scan_lines.inc) does not apply it stands aside and the
+    queue kernel answers: an empty ring (the reference's assertion must still fire), a target of more than
+    4095 slots (the entry's slot field), no cycles; and it does take what it is forced on - a target of 3000
+    slots in ten blocks, more targets in a block than its table holds (256), reads shorter than its first
+    round."""
+    rng = np.random.default_rng(11)
+    spec = synth.SynthSpec(seed=6, n_clusters=20011, row=101, plant_per_64k=20000, nocall_per_64k=1000)
+    L = 12
+    tb = TileBatch(sc, 2, L, spec.n_clusters)
+    tiles = [(1, 1101), (2, 1101)]
+    tb.fill_synthetic(spec, tiles, list(range(L)))
+    filt = synth.filter_bytes(spec, 1, 1101)
+    good = int(np.flatnonzero(filt & 1)[0])
+    try:
+        sc.set_option("line_walk", 1)
+        # an empty ring: :249's assertion, from the queue kernel
+        sc.set_targets(np.array([good], np.int32), np.array([[0, 1, 1]], np.int32), np.array([3], np.int32))
+        with pytest.raises(AssertionError):
+            tb.count(0, 0)
+        assert sc.get_option("line_walk_blocks") == 0
+        # 5000 slots in one target: beyond the entry's slot field
+        big = rng.integers(0, spec.n_clusters, 5000).astype(np.int32)
+        sc.set_targets(np.array([good], np.int32), np.array([[0, 5000]], np.int32), big)
+        want = tb.count(0, 0, per_target=True)
+        assert sc.get_option("line_walk_blocks") <= 0 and not sc.last_kernel().startswith("k_scan_lines")
+        del want
+        # 3000 slots in one target and 700 small targets around it, blocks of 300 pairs; then blocks of 5000
+        # pairs, which would hold more than 256 targets each and are cut short
+        T = 700
+        centre = np.concatenate([[good], rng.choice(np.setdiff1d(np.arange(spec.n_clusters), [good]), T - 1, replace=False)])
+        sizes = np.concatenate([[[1500, 1500]], rng.integers(1, 6, size=(T - 1, 2))])
+        lvl_off = np.zeros((T, 3), np.int32)
+        lvl_off[:, 1:] = np.cumsum(sizes, axis=1)
+        lvl_off += np.concatenate([[0], np.cumsum(sizes.sum(axis=1))[:-1]]).astype(np.int32)[:, None]
+        nbr = np.clip(np.repeat(centre, sizes.sum(axis=1)) + rng.integers(-150, 151, int(sizes.sum())), 0,
+                      spec.n_clusters - 1).astype(np.int32)
+        centre = centre.astype(np.int32)
+        sc.set_targets(centre, lvl_off, nbr)
+        host = [([synth.plane_bytes(spec, lane, tile, c) for c in range(L)], synth.filter_bytes(spec, lane, tile))
+                for lane, tile in tiles]
+        for mode, k in ((0, 0), (1, 1), (1, 3), (2, 2)):
+            for pairs in (300, 5000):
+                sc.set_option("line_pairs", pairs)
+                blocks, pt = tb.count(mode, k, per_target=True)
+                assert sc.last_kernel().startswith("k_scan_lines"), sc.last_kernel()
+                for i in range(2):
+                    valid, dups, lens, _ = oracle.count_tile(host[i][0], host[i][1], centre, lvl_off, nbr, mode, k)
+                    got = pt[i].astype(np.int64)
+                    got[got == INVALID_TARGET] = -1
+                    assert (got == np.where(valid[:, None] == 1, dups, -1)).all(), (mode, k, pairs)
+                    assert (blocks_to_reference(blocks[i], 2) == oracle.tally_tile(valid, dups, lens)).all()
+        # reads shorter than the first round (2 cycles against 5 for Levenshtein <= 2, 3 for Hamming <= 1)
+        tb2 = TileBatch(sc, 1, 2, spec.n_clusters)
+        tb2.fill_synthetic(spec, [(1, 1101)], [0, 1])
+        planes2 = [synth.plane_bytes(spec, 1, 1101, c) for c in range(2)]
+        for mode, k in ((0, 0), (1, 1), (2, 2)):
+            blocks, pt = tb2.count(mode, k, per_target=True)
+            assert sc.last_kernel().startswith("k_scan_lines")
+            valid, dups, lens, _ = oracle.count_tile(planes2, filt, centre, lvl_off, nbr, mode, k)
+            got = pt[0].astype(np.int64)
+            got[got == INVALID_TARGET] = -1
+            assert (got == np.where(valid[:, None] == 1, dups, -1)).all(), (mode, k)
+        tb2.free()
+    finally:
+        sc.set_option("line_walk", -1)
+        sc.set_option("line_pairs", 0)
+        tb.free()
+
+
 @pytest.mark.parametrize("sym", [1, 0])
 def test_dense_all_centres_small(sc, sym):
     """BASELINE config 5 in small: every well of a tile is a centre, 3 levels, 150 bp.  sym = 1: the

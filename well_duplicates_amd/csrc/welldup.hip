@@ -1942,7 +1942,8 @@ try {
     // would run (planes, early exit, equality / Hamming, or Levenshtein <= 2 by the closed form)
     bool use_lines = false;
     if (line_walk_wanted(ctx) && !use_dense && ws == 1 && ctx->queue_kernel && ctx->early_exit && L >= 1 && levels <= 8 &&
-        (use_queue || (lev && kk == 2 && ctx->lev2_closed && !lev_generic))) {
+        ((!lev && kk <= 254) || (lev && kk == 2 && ctx->lev2_closed && !lev_generic))) {
+        // (targets of more slots than the queue kernel's four passes hold, up to 4095, are the walk's too)
         if (int rc = build_line_tables(ctx))
             return rc;
         use_lines = ctx->lw_blocks > 0;
