@@ -66,6 +66,10 @@ typedef struct wd_ctx wd_ctx;
 
 /* ---- library / context ------------------------------------------------------------- */
 int wd_version(void);                    /* major*10000 + minor*100 + patch */
+/* sha256 (first 16 hex digits) of the sources the library was built from (csrc/ and this header), set at
+ * compile time: counter profiles and resource tables carry it, so that a measurement can be tied to the
+ * code that produced it and not merely to a kernel's name.  "unknown" for a build outside _lib.build(). */
+const char *wd_build_id(void);
 const char *wd_strerror(int code);
 const char *wd_last_error(const wd_ctx *ctx);
 
@@ -100,7 +104,9 @@ int wd_synchronize(wd_ctx *ctx);
  * "inflate_warm" (write-only: sets up the batch loaders' pinned ring, streams and events now instead of
  * inside the first batch; may be called from a thread of its own), "fast_inflate" (1:
  * the loaders try the library's own gunzip before zlib; the environment variable WD_FAST_INFLATE
- * sets the default), "well_stride" (1 = a plane per cycle; 4 = interleaved, see wd_interleave4).
+ * sets the default), "well_stride" (1 = a plane per cycle; 4 = interleaved, see wd_interleave4),
+ * "fast_exit" (0; 1 = the process exits right after wd_destroy: the call then waits for the device and
+ * frees nothing - no unpinning of the ingest ring, no stream destruction, 25 ms less per run).
  * Read-only (wd_get_option; -1 before the first dense scan of the current targets):
  * "dense_uniform_groups" (64-target groups of consecutive centres that share their neighbour
  * offsets), "dense_window_groups" (those scanned through signature windows in LDS),
@@ -297,6 +303,8 @@ typedef struct wd_hit {
     int32_t slot;      /* position in nbr[] */
     int32_t dist;      /* distance as the reference would print it (0 in WD_MODE_EQ) */
 } wd_hit;
+/* wd_hitlog_fetch copies min(total, max_records, capacity) records: when *total_out exceeds the capacity the
+ * log overflowed and the records beyond it are lost (wd_get_option "hitlog_capacity" reads the capacity). */
 int wd_hitlog_enable(wd_ctx *ctx, int64_t capacity);   /* 0 disables */
 int wd_hitlog_fetch(wd_ctx *ctx, wd_hit *out_host, int64_t max_records, int64_t *total_out);
 

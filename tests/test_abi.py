@@ -38,6 +38,13 @@ def test_error_strings_and_version(lib):
     assert lib.wd_strerror(-99) == b"unknown error"
 
 
+def test_build_id_is_the_hash_of_the_sources(lib):
+    """Counter profiles and resource tables carry wd_build_id(): it must name THIS tree's sources."""
+    bid = lib.wd_build_id().decode()
+    assert re.fullmatch(r"[0-9a-f]{16}", bid), bid
+    assert bid == _lib.source_build_id()
+
+
 def test_header_constants_match_binding():
     text = open(HEADER).read()
     consts = dict(re.findall(r"#define (WD_[A-Z_]+) \(?(-?\d+)\)?", text))

@@ -181,6 +181,53 @@ def test_cli_rank_that_fails_in_setup_takes_the_others_down(tmp_path_factory, tm
     assert not os.path.exists(report_file) or open(report_file).read() == ""
 
 
+def test_cli_rank_without_a_run_directory_takes_the_others_down(tmp_path_factory, tmp_path):
+    """Rank 1 is pointed at a run directory that does not exist (WD_TEST_RUN_SUFFIX: a per-rank suffix of
+    -r, test only): BCLReader raises on that rank alone, BEFORE anything of the scan - the process group is
+    up by then, so the error goes through the ranks' failure flag and both ranks end within seconds, not
+    after the rendezvous timeout (bcl_direct_reader.py:59-70)."""
+    import time
+    fx, run_dir = _run_dir(tmp_path_factory, "mid")
+    run = fx["runs"][0]
+    argv = ["-f", os.path.join(GOLD, fx["targets_file"]), "-n", str(fx["n_targets"]),
+            "-l", str(fx["levels"]), "-s", fx.get("stype", "hiseq_4000"), "-r", run_dir,
+            "-t", ",".join(fx["tiles"]), "-i", ",".join(str(l) for l in fx["lanes"])]
+    report_file = str(tmp_path / "report.txt")
+    argv += run["flags"] + ["--device", "0", "--dist-backend", "gloo", "-o", report_file, "-q"]
+    os.environ["WD_TEST_RUN_SUFFIX"] = "1:/no/such/run"
+    try:
+        t0 = time.time()
+        res = _torchrun(argv, 2)
+        took = time.time() - t0
+    finally:
+        del os.environ["WD_TEST_RUN_SUFFIX"]
+    assert res.returncode != 0
+    assert took < 120, took
+    err = res.stderr.decode()
+    assert "another rank failed" in err and ("FileNotFoundError" in err or "NotADirectoryError" in err), err[-1500:]
+    assert not os.path.exists(report_file) or open(report_file).read() == ""
+
+
+def test_cli_a_later_lane_that_fails_does_not_cost_an_earlier_lane_its_report(tmp_path_factory):
+    """Lanes 1,2,3 asked for on a run that has lanes 1 and 2 (the default -i is 1..8 on every flowcell):
+    the pipeline prefetches lane 3's first batch while lane 2 is still scanned, and get_tile raises for
+    the missing directory at once - but the reference writes a lane's report before it touches the next
+    (count_well_duplicates.py:207-226, :269), so lanes 1 and 2 are reported in full and only then does
+    the error of lane 3 surface."""
+    fx, run_dir = _run_dir(tmp_path_factory, "mid")
+    run = fx["runs"][0]
+    assert [str(l) for l in fx["lanes"]] == ["1", "2"]
+    argv = ["-f", os.path.join(GOLD, fx["targets_file"]), "-n", str(fx["n_targets"]),
+            "-l", str(fx["levels"]), "-s", fx.get("stype", "hiseq_4000"), "-r", run_dir,
+            "-t", ",".join(fx["tiles"]), "-i", "1,2,3"] + run["flags"]
+    for extra in ([], ["--tile-batch", "1"], ["--serial-ingest"]):
+        out, err = io.StringIO(), io.StringIO()
+        with redirect_stdout(out), redirect_stderr(err):
+            with pytest.raises((FileNotFoundError, RuntimeError)):
+                cwd.main(argv + extra)
+        assert out.getvalue() == run["stdout"], extra          # both good lanes, byte for byte
+
+
 def test_cli_missing_cycle_file_is_a_clean_error(tmp_path_factory):
     """A run folder that lacks one cycle's file of one tile: FileNotFoundError as in the reference
     (bcl_direct_reader.py:207-216) - raised only after every loader thread has finished, so

@@ -52,7 +52,7 @@ def test_fuzz(seed):
     rng = np.random.default_rng(9000 + seed)
     n = int(rng.choice([257, 1000, 4099, 20011]))
     L = int(rng.choice([1, 2, 3, 4, 7, 8, 9, 15, 16, 17, 31, 50, 63, 64, 65, 100]))
-    levels = int(rng.integers(1, 8))
+    levels = int(rng.integers(1, 13))            # (9+: beyond the 8-bit hit masks of the line walk and the dense path)
     T = int(rng.choice([1, 2, 63, 64, 65, 100, 255, 256, 257, 400])) if n > 500 else int(rng.integers(1, 200))
     T = min(T, n)
     kmode = str(rng.choice(["boundary", "tiny", "mixed"]))

@@ -32,8 +32,9 @@ def kernels(lib=None):
         cos = [f for f in os.listdir(tmp) if "gfx950" in f]
         if not cos:
             raise SystemExit("no gfx950 code object in %s" % lib)
-        notes = subprocess.run([os.path.join(LLVM, "llvm-readelf"), "--notes", os.path.join(tmp, cos[0])],
-                               check=True, capture_output=True, text=True).stdout
+        # one code object per translation unit of the library (csrc/welldup_*.hip)
+        notes = "\n".join(subprocess.run([os.path.join(LLVM, "llvm-readelf"), "--notes", os.path.join(tmp, co)],
+                                         check=True, capture_output=True, text=True).stdout for co in sorted(cos))
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
     out = {}
@@ -49,7 +50,16 @@ def kernels(lib=None):
         out[m.group(1)] = rec
     names = list(out)
     dem = subprocess.run(["c++filt"], input="\n".join(names), capture_output=True, text=True).stdout.split("\n")
-    return {d.replace("(ScanArgs)", "").replace("(anonymous namespace)::", ""): out[n] for n, d in zip(names, dem)}
+    return {d.replace("(ScanArgs)", "").replace("(LineArgs)", "").replace("(DenseArgs)", "")
+             .replace("(anonymous namespace)::", ""): out[n] for n, d in zip(names, dem)}
+
+
+def build_id(lib=None):
+    """wd_build_id() of the library the figures were read from (no GPU needed: a plain string getter)."""
+    import ctypes
+    h = ctypes.CDLL(lib or os.path.join(REPO, "well_duplicates_amd", "libwelldup.so"))
+    h.wd_build_id.restype = ctypes.c_char_p
+    return h.wd_build_id().decode()
 
 
 def main(argv):
@@ -58,7 +68,7 @@ def main(argv):
         i = argv.index("--json")
         js = argv[i + 1]
         argv = argv[:i] + argv[i + 2:]
-    pats = argv or ["k_scan_q", "k_dense_pairs", "k_dense_verify", "k_dense_pack", "k_dense_sig"]
+    pats = argv or ["k_scan_q", "k_scan_lines", "k_dense_"]
     ks = kernels()
     sel = {k: v for k, v in sorted(ks.items()) if any(p in k for p in pats)}
     print("%-58s %5s %5s %6s %6s %7s %8s" % ("kernel", "vgpr", "sgpr", "s.spill", "v.spill", "lds", "scratch"))
@@ -67,7 +77,7 @@ def main(argv):
                                                    v["lds_bytes"], v["scratch_bytes"]))
     if js:
         with open(js, "w") as fh:
-            json.dump(sel, fh, indent=1, sort_keys=True)
+            json.dump({"build_id": build_id(), "kernels": sel}, fh, indent=1, sort_keys=True)
     return 0
 
 

@@ -12,7 +12,7 @@ import subprocess
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 REPO = os.path.dirname(HERE)
-SRC = os.path.join(HERE, "csrc", "welldup.hip")
+CSRC = os.path.join(HERE, "csrc")
 INCLUDE = os.path.join(REPO, "include")
 # WELLDUP_LIB selects another build of the same ABI (kernel A/B experiments)
 LIB_PATH = os.environ.get("WELLDUP_LIB") or os.path.join(HERE, "libwelldup.so")
@@ -48,6 +48,7 @@ _pp = ctypes.POINTER(ctypes.c_void_p)
 # name -> (restype, argtypes); every symbol include/welldup.h declares
 PROTOTYPES = {
     "wd_version": (_i, []),
+    "wd_build_id": (ctypes.c_char_p, []),
     "wd_strerror": (ctypes.c_char_p, [_i]),
     "wd_last_error": (ctypes.c_char_p, [_vp]),
     "wd_create": (_vp, [_i]),
@@ -97,21 +98,80 @@ PROTOTYPES = {
 _lib = None
 
 
-def build(force: bool = False, verbose: bool = False) -> str:
-    """Compile csrc/welldup.hip for gfx950 into the package directory."""
-    hdr = os.path.join(INCLUDE, "welldup.h")
-    if not force and os.path.exists(LIB_PATH):
-        csrc = os.path.dirname(SRC)
-        newest = max([os.path.getmtime(hdr)] + [os.path.getmtime(os.path.join(csrc, f))
-                                                for f in os.listdir(csrc)])
-        if os.path.getmtime(LIB_PATH) >= newest:
-            return LIB_PATH
+UNITS = ("core", "scan", "queue", "lines", "dense", "ingest")      # csrc/welldup_<unit>.hip -> one object each
+OBJ_DIR = os.path.join(HERE, "build_obj")
+
+
+def _deps(path: str, seen=None) -> set:
+    """The file and every csrc/ or include/ file it #includes "by name", transitively."""
+    seen = set() if seen is None else seen
+    if path in seen or not os.path.exists(path):
+        return seen
+    seen.add(path)
+    with open(path, "r") as fh:
+        for line in fh:
+            line = line.strip()
+            if line.startswith('#include "'):
+                name = line.split('"')[1]
+                for base in (CSRC, INCLUDE):
+                    _deps(os.path.join(base, name), seen)
+    return seen
+
+
+def source_build_id() -> str:
+    """sha256 over the library's sources (csrc/*, include/welldup.h): what `wd_build_id()` of a library
+    built from this tree returns.  Counter profiles and resource tables carry it (tools/pmc_collect.py),
+    so that evidence is tied to the code that produced it, not to a kernel's name."""
+    import hashlib
+    h = hashlib.sha256()
+    files = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC)
+                   if f.endswith((".hip", ".inc", ".h")))
+    files.append(os.path.join(INCLUDE, "welldup.h"))
+    for f in files:
+        h.update(os.path.basename(f).encode() + b"\0")
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
+def build(force: bool = False, verbose: bool = False, jobs: int = 0) -> str:
+    """Compile csrc/welldup_*.hip for gfx950 (one object per unit, in parallel, only the units whose
+    sources changed) and link them into the package directory."""
+    import concurrent.futures
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-shared",
-           "-I" + INCLUDE, "-o", LIB_PATH, SRC, "-lz"]
+    bid = source_build_id()
+    os.makedirs(OBJ_DIR, exist_ok=True)
+    stamp = os.path.join(OBJ_DIR, "build_id")
+    stale_id = not os.path.exists(stamp) or open(stamp).read().strip() != bid
+    todo, objs = [], []
+    for u in UNITS:
+        src = os.path.join(CSRC, "welldup_%s.hip" % u)
+        obj = os.path.join(OBJ_DIR, u + ".o")
+        objs.append(obj)
+        newest = max(os.path.getmtime(f) for f in _deps(src))
+        # (the build id is compiled into the core unit only: four seconds, not a rebuild of every kernel)
+        if force or not os.path.exists(obj) or os.path.getmtime(obj) < newest or (u == "core" and stale_id):
+            todo.append((u, src, obj))
+    if not todo and os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(o) for o in objs):
+        return LIB_PATH
+
+    def compile_one(job):
+        u, src, obj = job
+        cmd = [hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-I" + INCLUDE,
+               '-DWD_BUILD_ID="%s"' % bid, "-c", src, "-o", obj]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+
+    n = jobs or min(len(todo), os.cpu_count() or 1) or 1
+    with concurrent.futures.ThreadPoolExecutor(n) as pool:
+        list(pool.map(compile_one, todo))
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_PATH] + objs + ["-lz"]
     if verbose:
-        print(" ".join(cmd))
+        print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)
+    with open(stamp, "w") as fh:
+        fh.write(bid + "\n")
     return LIB_PATH
 
 

@@ -165,10 +165,13 @@ def _decode_rows(rows: np.ndarray):
 class _Loading:
     """One batch of tiles on its way into HBM: the TileBatch and the loader pool's futures."""
 
-    def __init__(self, chunk, handles, tb, futures):
+    def __init__(self, chunk, handles, tb, futures, error=None):
         self.chunk, self.handles, self.tb, self.futures = chunk, handles, tb, futures
+        self.error = error                  # what submitting the batch raised (a missing lane directory, ...)
 
     def wait(self):
+        if self.error is not None:
+            raise self.error
         for f in self.futures:
             f.result()                      # re-raises the loader's exception (FileNotFoundError, ...)
 
@@ -190,7 +193,7 @@ def scan_lanes(sc: Scanner, reader, lane_tiles, cycle_list, mode, k, csr, wells,
     centre, lvl_off, nbr = csr
     levels = lvl_off.shape[1] - 1
     counts, logs = (into["counts"], into["logs"]) if into else ({}, {})
-    batches = []                            # (lane, [tiles]), never across a lane's end: an error stays its lane's
+    batches = []                            # (lane, [tiles]), never across a lane's end: an error stays its lane's (start_ahead)
     for lane, tiles in lane_tiles:
         if not tiles:
             continue
@@ -284,6 +287,17 @@ def scan_lanes(sc: Scanner, reader, lane_tiles, cycle_list, mode, k, csr, wells,
             planes = [pool.submit(load, i, c) for i, c in jobs]
         return _Loading((lane, chunk), handles, tb, filt + planes)
 
+    def start_ahead(batch):
+        """start(), for a batch that is not yet the current one: whatever submitting it raises (a lane
+        directory that does not exist, no .filter file, a tile of another size, an index beyond the tile)
+        is kept and raised when the batch's turn comes - the reference reports lane n before it touches
+        lane n + 1 (count_well_duplicates.py:207-226, :269), so an error of a later lane must not cost
+        an earlier lane its report."""
+        try:
+            return start(batch)
+        except Exception as e:              # noqa: BLE001 - re-raised by _Loading.wait()
+            return _Loading(batch, None, None, [], error=e)
+
     def release(tb, keep=False):
         live.remove(tb)
         if keep:
@@ -299,7 +313,7 @@ def scan_lanes(sc: Scanner, reader, lane_tiles, cycle_list, mode, k, csr, wells,
         depth = 3 if overlap else 1
         ahead = []
         for b in batches[:depth]:
-            ahead.append(start(b))
+            ahead.append(start_ahead(b))
         for bi in range(len(batches)):
             cur = ahead.pop(0)
             cur.wait()
@@ -325,7 +339,7 @@ def scan_lanes(sc: Scanner, reader, lane_tiles, cycle_list, mode, k, csr, wells,
                     seq_bytes[int(i)] = sc.gather_wells_batch(tb, int(i), ws)
             release(tb, keep=bi + depth < len(batches))
             if overlap and bi + depth < len(batches):
-                ahead.append(start(batches[bi + depth]))
+                ahead.append(start_ahead(batches[bi + depth]))
             for i, t in enumerate(chunk):
                 counts[(lane, t)] = report.TileCounts.from_block(blocks[i], levels)
                 if want_log:
@@ -348,7 +362,7 @@ def scan_lanes(sc: Scanner, reader, lane_tiles, cycle_list, mode, k, csr, wells,
             if lane_done is not None and last_batch_of[lane] == bi:
                 lane_done(lane)
             if not overlap and bi + 1 < len(batches):
-                ahead.append(start(batches[bi + 1]))
+                ahead.append(start_ahead(batches[bi + 1]))
     finally:
         # queued loads are dropped, running ones finish - only then may their targets go
         pool.shutdown(wait=True, cancel_futures=True)
@@ -359,11 +373,14 @@ def scan_lanes(sc: Scanner, reader, lane_tiles, cycle_list, mode, k, csr, wells,
     return counts, logs
 
 
-def main(argv=None):
+def main(argv=None, exiting=False):
+    """exiting=True (what `python -m well_duplicates_amd.count_well_duplicates` passes): the process ends
+    when this returns, so the GPU context is closed without freeing its buffers one by one."""
     if os.environ.get("WD_CLI_TIMING"):
         import time
         _T0[0] = time.perf_counter()
     args = parse_args(argv)
+    args.exiting = bool(exiting)
     log = (lambda msg: None) if args.quiet else (lambda msg: print(str(msg), file=sys.stderr))
 
     # The GPU context first (this thread's current device is its device from here on), so that the batch
@@ -396,38 +413,15 @@ def main(argv=None):
         if opener is not None:
             opener.join()
         if early["sc"] is not None:
-            early["sc"].close()                 # (a second close is a no-op)
+            early["sc"].close(exiting=args.exiting)     # (a second close is a no-op)
 
 
 def _main(args, log, wdist, rank, world, device, opener, early):
 
-    lanes = args.lane.split(",") if args.lane else range(1, 8 + 1)
-    tiles = workload.tiles_for_stype(args.stype)
-    if args.tile_id:
-        tiles = workload.filter_tiles(tiles, args.tile_id, args.stype)
-    cycles = workload.parse_cycles(args.start, args.end, args.cycles)
-    cycle_list = [c for s, e in cycles for c in range(s, e)]
-    mode, k = compare_mode(args.edit_distance, args.hamming)
-
-    if args.all_wells:
-        from . import cluster_indexes
-        xy = cluster_indexes.read_slocs(args.slocs or os.path.join(args.run, "Data", "Intensities", "s.locs"))
-        targets = csr = None
-        wells = np.zeros(0, dtype=np.int64)
-    else:
-        # a regular targets file is parsed in bulk; anything else goes through the reference's parser,
-        # which raises what the reference raises
-        fast = load_targets_csr(args.coord_file, args.level, args.sample_size)
-        if fast is not None:
-            targets, n_parsed, csr = None, fast[0], fast[1:]
-        else:
-            targets = load_targets(filename=args.coord_file, levels=args.level + 1, limit=args.sample_size)
-            n_parsed, csr = len(targets), targets.to_csr(args.level)
-        # every well some target touches = targets.get_all_indices(), sorted (the rings loaded are 1..-l)
-        wells = np.unique(np.concatenate([csr[0], csr[2]]).astype(np.int64))
-    reader = bcl_direct_reader.BCLReader(args.run)
-    _lap("targets file, run directory")
-
+    # Under torchrun the process group comes FIRST: whatever a rank's setup raises after this point - a
+    # run directory it cannot list, a targets file it cannot parse, a GPU it cannot use - goes through the
+    # ranks' one failure flag below, and the others end with it instead of waiting in the rendezvous for a
+    # rank that has already left (bcl_direct_reader.py:59-70 and target.py:6-40 raise on the first bad path).
     if world > 1:
         import torch
         import torch.distributed as tdist
@@ -437,12 +431,48 @@ def _main(args, log, wdist, rank, world, device, opener, early):
         else:
             tdist.init_process_group("gloo")            # gloo; "wd": the bootstrap channel of the unique id
     levels = args.level
-    out_fh = open(args.output, "w") if (args.output and rank == 0) else None
+    out_fh = None
     try:
-        # a rank whose setup fails (no memory on its GPU, a bad device, targets it cannot upload) must
-        # not leave the others waiting in the first collective: setup and scan feed ONE failure flag
+        # a rank whose setup fails (an unreadable run directory, no memory on its GPU, a bad device, targets
+        # it cannot upload) must not leave the others waiting in the first collective: setup and scan feed
+        # ONE failure flag
         sc, err = None, None
+        lanes, tiles, cycles, cycle_list, mode, k = [], [], [], [], 0, 0
+        reader = csr = None
+        wells = np.zeros(0, dtype=np.int64)
+        n_targets = 0
         try:
+            lanes = args.lane.split(",") if args.lane else range(1, 8 + 1)
+            tiles = workload.tiles_for_stype(args.stype)
+            if args.tile_id:
+                tiles = workload.filter_tiles(tiles, args.tile_id, args.stype)
+            cycles = workload.parse_cycles(args.start, args.end, args.cycles)
+            cycle_list = [c for s, e in cycles for c in range(s, e)]
+            mode, k = compare_mode(args.edit_distance, args.hamming)
+
+            if args.all_wells:
+                from . import cluster_indexes
+                xy = cluster_indexes.read_slocs(args.slocs or os.path.join(args.run, "Data", "Intensities", "s.locs"))
+            else:
+                # a regular targets file is parsed in bulk; anything else goes through the reference's parser,
+                # which raises what the reference raises
+                fast = load_targets_csr(args.coord_file, args.level, args.sample_size)
+                if fast is not None:
+                    n_parsed, csr = fast[0], fast[1:]
+                else:
+                    targets = load_targets(filename=args.coord_file, levels=args.level + 1, limit=args.sample_size)
+                    n_parsed, csr = len(targets), targets.to_csr(args.level)
+                # every well some target touches = targets.get_all_indices(), sorted (the rings loaded are 1..-l)
+                wells = np.unique(np.concatenate([csr[0], csr[2]]).astype(np.int64))
+            run_path = args.run
+            if os.environ.get("WD_TEST_RUN_SUFFIX"):        # (tests: "<rank>:<suffix>" breaks one rank's run path)
+                r_, _, suffix = os.environ["WD_TEST_RUN_SUFFIX"].partition(":")
+                if int(r_) == rank:
+                    run_path = run_path + suffix
+            reader = bcl_direct_reader.BCLReader(run_path)
+            _lap("targets file, run directory")
+            if args.output and rank == 0:
+                out_fh = open(args.output, "w")
             if opener is not None:
                 opener.join()
             if early["err"] is not None:
@@ -519,7 +549,7 @@ def _main(args, log, wdist, rank, world, device, opener, early):
         finally:
             _lap("reports")
             if sc is not None:
-                sc.close()
+                sc.close(exiting=args.exiting)
     finally:
         _lap("context closed")
         if out_fh:
@@ -531,4 +561,4 @@ def _main(args, log, wdist, rank, world, device, opener, early):
 
 
 if __name__ == "__main__":
-    sys.exit(main())
+    sys.exit(main(exiting=True))

@@ -83,10 +83,15 @@ class Scanner:
         if rc != _lib.OK:
             _raise(self._lib, self._ctx, rc)
 
-    def close(self):
+    def close(self, exiting: bool = False):
+        """Destroys the context.  exiting=True: the process ends right after (the CLI's case) - the library
+        then only waits for the device and leaves the freeing to the driver ("fast_exit", include/welldup.h)."""
         if self._ctx:
-            for p in list(self._owned):
-                self._lib.wd_free(self._ctx, p)
+            if exiting:
+                self._lib.wd_set_option(self._ctx, b"fast_exit", 1)
+            else:
+                for p in list(self._owned):
+                    self._lib.wd_free(self._ctx, p)
             self._owned.clear()
             self._lib.wd_destroy(self._ctx)
             self._ctx = None
@@ -340,7 +345,9 @@ class Scanner:
         first, so the host buffer is as large as the records there are, not as the log could hold."""
         total = ctypes.c_int64()
         self._ck(self._lib.wd_hitlog_fetch(self._ctx, None, 0, ctypes.byref(total)))
-        n = max(0, min(total.value, int(max_records)))
+        # (the library copies at most what the device log held: records beyond its capacity were counted,
+        # not kept - the caller sees that in total > len(records))
+        n = max(0, min(total.value, int(max_records), self.get_option("hitlog_capacity")))
         dt = np.dtype([("tile", "<i4"), ("target", "<i4"), ("slot", "<i4"), ("dist", "<i4")])
         recs = np.zeros(n, dtype=dt)
         if n:

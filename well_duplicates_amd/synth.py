@@ -27,7 +27,7 @@ import numpy as np
 
 M64 = (1 << 64) - 1
 
-# Multipliers (odd 64-bit constants).  The HIP generator in csrc/welldup.hip uses the same.
+# Multipliers (odd 64-bit constants).  The HIP generator in csrc/synth_kernels.inc uses the same.
 K_SEED = 0x9E3779B97F4A7C15
 K_LANE = 0xD1B54A32D192ED03
 K_TILE = 0x8CB92BA72F3D8DD7
