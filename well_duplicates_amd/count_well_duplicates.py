@@ -525,12 +525,13 @@ def _main(args, log, wdist, rank, world, device, opener, early):
                     if world == 1:          # as the reference: a lane is reported when it is done
                         emit(lane, rows)
 
-                scan_lanes(sc, reader, lane_tiles, cycle_list, mode, k, csr, wells,
-                           max(0, args.tile_batch), args.threads,
-                           0 if (args.quiet or args.all_wells) else len(cycles),
-                           overlap=not args.serial_ingest,
-                           interleave=4 if args.layout == "interleaved" else 1,
-                           gpu_inflate=not args.host_inflate, lane_done=lane_done, into=results)
+                if err is None:             # (a rank whose setup failed has nothing to scan: it goes to the flag)
+                    scan_lanes(sc, reader, lane_tiles, cycle_list, mode, k, csr, wells,
+                               max(0, args.tile_batch), args.threads,
+                               0 if (args.quiet or args.all_wells) else len(cycles),
+                               overlap=not args.serial_ingest,
+                               interleave=4 if args.layout == "interleaved" else 1,
+                               gpu_inflate=not args.host_inflate, lane_done=lane_done, into=results)
             except Exception as e:          # noqa: BLE001 - re-raised below, on every rank
                 err = e
             if world > 1:
