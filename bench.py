@@ -93,7 +93,14 @@ def parse(argv=None):
                          "rehearsal of the multi-rank logic with several ranks on ONE GPU")
     ap.add_argument("--master-port", type=int, default=0,
                     help="rendezvous port when bench.py starts its own ranks (0 = a free one)")
-    ap.add_argument("--first-lane", type=int, default=1, help="rank r scans lane FIRST_LANE + r")
+    ap.add_argument("--first-lane", type=int, default=1, help="rank r scans lane FIRST_LANE + r (x LANES_PER_RANK)")
+    ap.add_argument("--lanes-per-rank", type=int, default=1,
+                    help="lanes resident on one rank's GPU and scanned per step (default 1: BASELINE's one lane per "
+                         "GPU).  8 on one rank = the whole of BASELINE configs[2]'s input (8 lanes x 112 tiles, 193 GB) "
+                         "on one MI355X; 2 on 4 ranks = the same flowcell over four processes")
+    ap.add_argument("--check-tiles", type=int, default=0,
+                    help="after the timed region, rank 0 checks this many tiles, sampled over ALL ranks' rows of the "
+                         "merged block, against the C oracle (the planes are regenerated on the host from the spec)")
     ap.add_argument("--dump-block", default=None,
                     help="rank 0 saves the last step's merged [ranks*tiles, 1+5*levels] counter block here (.npy)")
     ap.add_argument("--dry-run", action="store_true",
@@ -576,16 +583,23 @@ def main(argv=None):
     t0 = time.time()
     centre, lvl_off, nbr = workload.honeycomb_targets(rows, cols, T, levels, seed=13)
     spec = synth.SynthSpec(seed=2, n_clusters=n_clusters, row=cols)
-    lane = args.first_lane + rank
+    lpr = max(1, args.lanes_per_rank)
+    lane = args.first_lane + rank * lpr
     if args.stype is None:                                    # the layout BASELINE names for this N
-        args.stype = "hiseq_x" if world == 1 else "hiseq_4000"
+        args.stype = "hiseq_x" if world * lpr == 1 else "hiseq_4000"
     tile_ids = [int(t) for t in workload.tiles_for_stype(args.stype)]
-    if args.tiles is None:
-        args.tiles = len(tile_ids)
     per_lane = len(tile_ids)
+    if args.tiles is None:
+        args.tiles = per_lane * lpr
     tile_ids = (tile_ids * ((args.tiles + per_lane - 1) // per_lane))[:args.tiles]
-    # repeated ids (only if --tiles exceeds a lane) get distinct lanes so no two tiles share data
-    lane_tile = [(lane + 8 * (i // per_lane), t) for i, t in enumerate(tile_ids)]
+
+    def lane_tiles_of(r):
+        """(lane, tile) of every row rank r owns: its lanes one after the other; ids that repeat beyond them
+        (only if --tiles exceeds the rank's lanes) get lanes of their own so that no two tiles share data."""
+        first = args.first_lane + r * lpr
+        return [(first + j if j < lpr else first + (j % lpr) + 8 * max(1, world * lpr // 8 + 1) * (j // lpr), t)
+                for j, t in ((i // per_lane, t) for i, t in enumerate(tile_ids))]
+    lane_tile = lane_tiles_of(rank)
 
     # One explicit stream for everything in a step (scan kernels, torch ops, the collective's
     # stream dependencies).  The scanner must NOT be left on its own stream here: torch's
@@ -931,6 +945,29 @@ def main(argv=None):
                   "sample": "first %d targets of 1 tile (%d compares) in %.2f s, pure-Python restatement of "
                             "get_seqs + the compare loop, planes already gunzipped" % (n_py, py_compares, t_py)}
 
+    # ---- --check-tiles: sampled rows of the MERGED block (every rank's) against the oracle ----
+    checked = None
+    if rank == 0 and args.check_tiles > 0:
+        from oracle import oracle
+        rng = np.random.default_rng(5)
+        total_rows = world * args.tiles
+        pick = sorted(rng.choice(total_rows, size=min(args.check_tiles, total_rows), replace=False).tolist())
+        wells_u = np.unique(np.concatenate([centre, nbr]).astype(np.int64))
+        c2 = np.searchsorted(wells_u, centre).astype(np.int32)
+        n2 = np.searchsorted(wells_u, nbr).astype(np.int32)
+        planes_h, filters_h = [], []
+        for row in pick:                     # (only the wells the targets touch: the oracle reads no others)
+            ln, t = lane_tiles_of(row // args.tiles)[row % args.tiles]
+            planes_h.append([synth.plane_bytes(spec, ln, t, c, wells_u) for c in range(L)])
+            filters_h.append(synth.filter_bytes(spec, ln, t, wells_u))
+        out = oracle.count_tiles_mt(planes_h, filters_h, c2, lvl_off, n2, mode, k, min(16, len(pick)))
+        dev = counts[pick].copy()
+        dev[:, 1 + 3 * levels:1 + 4 * levels] = np.cumsum(dev[:, 1 + 3 * levels:1 + 4 * levels], axis=1)
+        dev[:, 1 + 4 * levels:] = np.cumsum(dev[:, 1 + 4 * levels:][:, ::-1], axis=1)[:, ::-1]
+        if not (dev == out).all():
+            raise SystemExit("bench: merged block differs from the CPU oracle on sampled tiles %s" % pick)
+        checked = {"rows": pick, "ranks_covered": sorted({r // args.tiles for r in pick}), "oracle": "count_tiles_mt"}
+
     e2e = None
     if rank == 0 and world == 1 and args.e2e_tiles > 0 and args.profile_steps > 0 and args.mode == "eq":
         tb.free()                                             # (the e2e run brings its own tiles)
@@ -938,8 +975,10 @@ def main(argv=None):
         e2e = e2e_probe(local_rank, args.e2e_tiles, rows, cols, centre, lvl_off, nbr)
     if rank == 0:
         per_lane = len(workload.tiles_for_stype(args.stype))
-        named = {("hiseq_x", 96): "BASELINE configs[1]", ("hiseq_4000", 112): "BASELINE configs[2] layout"}.get(
-            (args.stype, args.tiles), "custom layout")
+        named = {("hiseq_x", 96, 1): "BASELINE configs[1]", ("hiseq_4000", 112, 1): "BASELINE configs[2] layout"}.get(
+            (args.stype, args.tiles, lpr), "custom layout")
+        if args.stype == "hiseq_4000" and world * lpr == 8 and args.tiles == 112 * lpr:
+            named = "BASELINE configs[2]: 8 lanes x 112 tiles" + ("" if lpr == 1 else ", %d lanes per rank" % lpr)
         line = {
             "metric": "target x neighbour seq-compares/sec (whole node)",
             "value": round(value, 1), "unit": "compares/s",
@@ -947,8 +986,11 @@ def main(argv=None):
             "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 5), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-            "config": {"workload": "%d lane(s) x %d tiles (%s) x %d targets x %d levels, %d bp; one lane per GPU (%s)"
-                                   % (world, args.tiles, args.stype, T, levels, L, named),
+            "config": {"workload": "%d lane(s) x %d tiles (%s) x %d targets x %d levels, %d bp; %s per GPU (%s)"
+                                   % (world * lpr, args.tiles // lpr, args.stype, T, levels, L,
+                                      "one lane" if lpr == 1 else "%d lanes" % lpr, named),
+                       "lanes_per_rank": lpr, "resident_bytes_per_rank": args.tiles * (L + 1) * n_clusters,
+                       "checked_against_oracle": checked,
                        "mode": args.mode, "k": k, "early_exit": not args.no_early_exit,
                        "clusters_per_tile": n_clusters, "compares_per_step": compares_all,
                        "valid_targets_per_rank": valid_rank, "parallelism": "tiles sharded, %d rank(s)" % world,

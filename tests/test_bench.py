@@ -94,3 +94,41 @@ def test_two_ranks_on_one_gpu_match_one_rank_runs(tmp_path):
     r = _run(["--gpus", "2", "--backend", "gloo", "--merge-every", "1"] + common + ["--dump-block", three])
     assert r.returncode == 0, r.stderr[-4000:]
     assert (np.load(three) == merged).all()
+
+
+@pytest.mark.gpu
+def test_configs2_at_its_own_shape_on_one_gpu(tmp_path):
+    """BASELINE configs[2] - 8 lanes x 112 tiles (HiSeq 4000), 2500 targets x 5 levels, 50 bp: 193 GB of planes,
+    which one MI355X holds - at its OWN shape on the one GPU a lease has:
+      (a) one process, eight lanes resident, one scan of 896 tiles per step;
+      (b) four ranks x two lanes over gloo: the job blocks, the [896, 26] merge and the memory of a multi-rank
+          run at that shape, sixteen tiles sampled over every rank's rows checked against the oracle;
+    Both produce the same rows, lane by lane.  Four ranks, not eight: this pool's process guard ends a run in
+    which more than six processes have the card open, and the test runner and the launcher count (a run with
+    six ranks was ended that way).  The eight-rank process layout itself - a job per lane, as the reference
+    runs it: Snakefile.count_dups:25, :153-160 - is rehearsed on the CPU
+    (tests/test_dist.py::test_world_of_eight_at_the_configs2_shape)."""
+    common = ["--stype", "hiseq_4000", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--profile-steps", "0"]
+    one = str(tmp_path / "one.npy")
+    p = _run(["--gpus", "1", "--lanes-per-rank", "8"] + common + ["--dump-block", one], timeout=1200)
+    assert p.returncode == 0, p.stderr[-4000:]
+    a = _last_json(p.stdout)
+    assert a["config"]["workload"].startswith("8 lane(s) x 112 tiles (hiseq_4000)")
+    assert a["config"]["resident_bytes_per_rank"] > 190e9
+    whole = np.load(one)
+    assert whole.shape == (896, 26) and (whole[:, 0] > 0).all()
+    four = str(tmp_path / "four.npy")
+    q = _run(["--gpus", "4", "--lanes-per-rank", "2", "--backend", "gloo", "--check-tiles", "16"] + common +
+             ["--dump-block", four], timeout=1200)
+    assert q.returncode == 0, q.stderr[-4000:]
+    b = _last_json(q.stdout)
+    assert b["n_gpus"] == 4 and b["rccl_world"] == 4
+    assert b["config"]["process_group"]["allreduce_of_ones"] == 4
+    assert "BASELINE configs[2]" in b["config"]["workload"]
+    chk = b["config"]["checked_against_oracle"]
+    assert len(chk["rows"]) == 16 and chk["ranks_covered"] == [0, 1, 2, 3]
+    assert (np.load(four) == whole).all()
+    assert b["config"]["compares_per_step"] == int(whole[:, 1:6].sum()) == a["config"]["compares_per_step"]
+    for lane in range(8):                                     # eight different lanes, not one lane eight times
+        for other in range(lane):
+            assert (whole[lane * 112:(lane + 1) * 112] != whole[other * 112:(other + 1) * 112]).any()

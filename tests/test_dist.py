@@ -102,3 +102,50 @@ def test_shard_bounds_cover_everything():
                 assert 0 <= hi - lo <= n // world + 1
             assert seen == list(range(n))
     assert wdist.shard(list("abcdefg"), 1, 3) == ["c", "d"]
+
+
+def _worker8(rank, world, port, out_dir):
+    """A rank of the BASELINE configs[2] world: 8 ranks, 8 lanes x 112 tiles, 5 levels - its rows are a
+    function of (lane, tile) that no other rank can produce, so the merged block shows who wrote what."""
+    sys.path.insert(0, REPO)
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank),
+                      WORLD_SIZE=str(world), LOCAL_RANK=str(rank), LOCAL_WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from well_duplicates_amd import count_well_duplicates as cwd
+    from well_duplicates_amd import workload
+    tiles = workload.tiles_for_stype("hiseq_4000")
+    items = [(lane, t) for lane in range(1, 9) for t in tiles]
+    r, w, _ = wdist.env_rank()
+    mine = wdist.shard(items, r, w)
+    assert len(mine) == 112 and {lane for lane, _ in mine} == {rank + 1}      # a lane per rank, as the reference's jobs
+    rows = np.array([[int(lane) * 100000 + int(t) * 7 + c for c in range(26)] for lane, t in mine], dtype=np.int64)
+    assert not wdist.any_rank_failed(False, w)
+    assert wdist.any_rank_failed(rank == 5, w)
+    full = wdist.merge_blocks(rows, len(items), r, w, backend="gloo")
+    logs = wdist.gather_dicts({item: ["rank %d" % rank] for item in mine[:3]}, w)
+    assert len(logs) == 24
+    assert wdist.max_over_ranks(float(rank), w) == 7.0
+    # eight ranks of one node share the host's cores: the reader threads are this rank's share of them
+    cpus = len(os.sched_getaffinity(0))
+    assert cwd.default_threads() == max(1, min(32, cpus // 8))
+    np.save(os.path.join(out_dir, "full8_%d.npy" % rank), full)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_world_of_eight_at_the_configs2_shape(tmp_path):
+    """BASELINE configs[2]'s process layout on CPU: 8 gloo ranks, the flat list of 8 x 112 (lane, tile) items
+    block-sharded so that rank r owns lane r + 1 (Snakefile.count_dups:25, :153-160: a job per lane), ONE
+    all-reduce of the [896, 26] block, the failure flag, the gather of the log lines, the reader-thread
+    share at LOCAL_WORLD_SIZE = 8.  (The GPU side of this shape runs in tests/test_bench.py.)"""
+    import torch.multiprocessing as mp
+    from well_duplicates_amd import workload
+    world = 8
+    mp.spawn(_worker8, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    tiles = workload.tiles_for_stype("hiseq_4000")
+    items = [(lane, t) for lane in range(1, 9) for t in tiles]
+    want = np.array([[int(lane) * 100000 + int(t) * 7 + c for c in range(26)] for lane, t in items], dtype=np.int64)
+    assert want.shape == (896, 26)
+    for rank in range(world):
+        assert (np.load(tmp_path / ("full8_%d.npy" % rank)) == want).all()

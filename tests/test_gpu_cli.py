@@ -116,9 +116,10 @@ def _torchrun(argv, nproc):
                           cwd=repo, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
 
 
-@pytest.mark.parametrize("name,run_idx,nproc", [("mid", 2, 2), ("mid", 0, 3), ("far", 2, 2)])
+@pytest.mark.parametrize("name,run_idx,nproc", [("mid", 2, 2), ("mid", 0, 3), ("far", 2, 2), ("mid", 2, 4)])
 def test_cli_ranks_share_one_gpu(tmp_path_factory, tmp_path, name, run_idx, nproc):
-    """torchrun with 2 and 3 ranks (all on GPU 0, gloo for the collective): the flat (lane, tile)
+    """torchrun with 2, 3 and 4 ranks (all on GPU 0, gloo for the collective; four ranks, the launcher and
+    the test runner are the six processes this pool lets share one card): the flat (lane, tile)
     list - 2 lanes x 2 tiles for `mid`, so ranks own parts of different lanes - is sharded, ONE
     all-reduce merges the rows, and rank 0 prints the lanes in order: report and duplicate log
     equal the reference's single-process output."""
@@ -136,6 +137,27 @@ def test_cli_ranks_share_one_gpu(tmp_path_factory, tmp_path, name, run_idx, npro
     keep = ("center seq at", "well seq at", "edit distance:")
     log = [ln for ln in res.stderr.decode().splitlines() if ln.startswith(keep)]
     assert log == run["dup_log"]
+
+
+def test_cli_ranks_that_own_nothing(tmp_path_factory, tmp_path):
+    """Two (lane, tile) items over four ranks: ranks 1 and 3 own nothing (shard_bounds gives them empty
+    blocks), as ranks of an eight-GPU node do on a run of a few tiles - they create their context, set the
+    targets, skip the scan and take part in the flag, the merge and the gather.  Report and log equal the
+    single-process run of the same tiles."""
+    fx, run_dir = _run_dir(tmp_path_factory, "mid")
+    run = fx["runs"][2]
+    one_tile = dict(fx, tiles=fx["tiles"][:1])
+    want_out, want_err = _cli(one_tile, run_dir, run)
+    argv = ["-f", os.path.join(GOLD, fx["targets_file"]), "-n", str(fx["n_targets"]),
+            "-l", str(fx["levels"]), "-s", fx.get("stype", "hiseq_4000"), "-r", run_dir,
+            "-t", fx["tiles"][0], "-i", ",".join(str(l) for l in fx["lanes"])]
+    report_file = str(tmp_path / "report.txt")
+    res = _torchrun(argv + run["flags"] + ["--device", "0", "--dist-backend", "gloo", "-o", report_file], 4)
+    assert res.returncode == 0, res.stderr.decode()[-2000:]
+    assert open(report_file).read() == want_out
+    keep = ("center seq at", "well seq at", "edit distance:")
+    assert [ln for ln in res.stderr.decode().splitlines() if ln.startswith(keep)] == \
+        [ln for ln in want_err.splitlines() if ln.startswith(keep)]
 
 
 def test_cli_failing_rank_takes_the_others_down(tmp_path_factory, tmp_path):
