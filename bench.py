@@ -25,7 +25,7 @@ Extra objects on the JSON line:
                 cost the step 6 %), `region_ms_per_launch` = one event pair around the whole region; `traffic` = HBM bytes per launch from
                 the PMC counters of the same kernel on the same workload (profiles/traffic.json,
                 `traffic_source` says which run - null if that run profiled another kernel than the one
-                this run launched), `l2_miss_frac` = traffic / kernel time / peak (L2-miss bytes: the
+                this run launched, or another build of it: the library's per-unit source hash, wd_build_id), `l2_miss_frac` = traffic / kernel time / peak (L2-miss bytes: the
                 Infinity Cache sits behind the L2); `two_lanes_alternating` = the same launches over two
                 resident lanes, the control for what the cache keeps between steps.
   cpu_baseline  the C oracle (oracle/welldup_oracle.c, -O3, OpenMP over tiles) on a bounded
@@ -168,6 +168,14 @@ def traffic_lookup(key, tiles, kernel):
         return None, "no counter run for %s in profiles/traffic.json" % key
     if entry.get("kernel") != kernel:
         return None, "stale counter run: %s profiled %s, this run launched %s" % (entry["source"], entry.get("kernel"), kernel)
+    # ... and only if that kernel's CODE is the code that was profiled: the library carries a hash of the
+    # sources of each translation unit (wd_build_id), the counter run recorded the one it saw
+    from well_duplicates_amd import _lib
+    unit = _lib.unit_of_kernel(kernel)
+    here = _lib.build_ids().get(unit)
+    if entry.get("unit_id") != here:
+        return None, "stale counter run: %s profiled unit %s at %s, this library's is %s" % (
+            entry["source"], unit, entry.get("unit_id"), here)
     src = "%s [%s, %s]" % (entry["source"], key, kernel)
     if entry["tiles_measured"] != tiles:
         src += ", per-tile bytes of the %d-tile counter run x %d tiles" % (entry["tiles_measured"], tiles)
@@ -883,6 +891,11 @@ def main(argv=None):
     roofline = {"bound": "hbm", "kernel": headline_kernel, "achieved": round(achieved, 2),
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                 **traffic_fields(traffic, traffic_source, kern_ms),
+                "build_id": __import__("well_duplicates_amd._lib", fromlist=["_lib"]).build_ids(),
+                "achieved_is": "ALGORITHMIC bytes per launch (SURVEY.md 8d: 54 B per compare + 55 B per valid target "
+                               "+ the counter rows) / the kernel's mean duration - the figure the contract asks for, not "
+                               "a counter reading: a lazy kernel moves fewer bytes than the model charges, `traffic` / "
+                               "`l2_miss_frac` beside it are the measured ones",
                 "traffic_is": "L2-miss bytes per launch (2 x FETCH_SIZE + WRITE_SIZE of the PMC passes): an upper bound of "
                               "the HBM bytes, the Infinity Cache sits behind the L2",
                 "two_lanes_alternating": two_lanes,

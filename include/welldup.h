@@ -66,9 +66,12 @@ typedef struct wd_ctx wd_ctx;
 
 /* ---- library / context ------------------------------------------------------------- */
 int wd_version(void);                    /* major*10000 + minor*100 + patch */
-/* sha256 (first 16 hex digits) of the sources the library was built from (csrc/ and this header), set at
- * compile time: counter profiles and resource tables carry it, so that a measurement can be tied to the
- * code that produced it and not merely to a kernel's name.  "unknown" for a build outside _lib.build(). */
+/* Hashes of the sources the library was built from, set at compile time: "<id> core=<id> scan=<id> queue=<id>
+ * lines=<id> dense=<id> ingest=<id>" - sha256 (first 16 hex digits) of all of csrc/ and this header, then of
+ * each translation unit's own sources (csrc/welldup_<unit>.hip and what it includes).  Counter profiles and
+ * resource tables carry them, so that a measurement is tied to the code that produced it and not merely to a
+ * kernel's name: bench.py quotes a counter run only if the unit the kernel lives in is unchanged.
+ * "unknown" for a build outside _lib.build(). */
 const char *wd_build_id(void);
 const char *wd_strerror(int code);
 const char *wd_last_error(const wd_ctx *ctx);

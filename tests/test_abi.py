@@ -40,9 +40,17 @@ def test_error_strings_and_version(lib):
 
 def test_build_id_is_the_hash_of_the_sources(lib):
     """Counter profiles and resource tables carry wd_build_id(): it must name THIS tree's sources."""
-    bid = lib.wd_build_id().decode()
-    assert re.fullmatch(r"[0-9a-f]{16}", bid), bid
-    assert bid == _lib.source_build_id()
+    ids = _lib.build_ids()
+    assert re.fullmatch(r"[0-9a-f]{16}", ids["all"]), ids
+    assert ids["all"] == _lib.source_build_id()
+    units = _lib.source_unit_ids()
+    assert sorted(units) == sorted(_lib.UNITS)
+    for u, h in units.items():
+        assert ids[u] == h, (u, ids)
+    assert _lib.unit_of_kernel("k_scan_q<true, 2, 0, 1>, targets sorted by centre") == "queue"
+    assert _lib.unit_of_kernel("k_scan_lines<true, 5, -1>") == "lines"
+    assert _lib.unit_of_kernel("dense chain v5, equality") == "dense"
+    assert _lib.unit_of_kernel("k_scan<HamState, true, 4, 4>") == "scan"
 
 
 def test_header_constants_match_binding():

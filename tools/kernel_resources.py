@@ -59,7 +59,7 @@ def build_id(lib=None):
     import ctypes
     h = ctypes.CDLL(lib or os.path.join(REPO, "well_duplicates_amd", "libwelldup.so"))
     h.wd_build_id.restype = ctypes.c_char_p
-    return h.wd_build_id().decode()
+    return h.wd_build_id().decode()           # "<all> core=<id> scan=<id> ..." (include/welldup.h)
 
 
 def main(argv):

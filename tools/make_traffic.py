@@ -39,13 +39,16 @@ def main():
             key += "_plant%d" % probe["plant_per_64k"]
         # the compare kernel the probe's library said it launched (wd_last_kernel; runs older than that
         # entry point: the scan kernel's name as the profiler recorded it) - bench.py quotes these
-        # bytes only for a run whose library reports the same kernel
+        # bytes only for a run whose library reports the same kernel AND the same hash of that kernel's
+        # translation unit (unit_id: wd_build_id; runs older than round 4 carry none and read as stale)
         scan = [k for k in kernels if k.startswith(("k_scan_q<", "k_scan<"))]
         kernel = probe.get("kernel") or (scan[0] if len(scan) == 1 else None)
         if kernel is None and probe["workload"] == "dense":         # round 2's chain (kDenseChainVersion 2)
             kernel = "dense chain v2, %s (k_dense_sig .. k_dense_reduce)" % (
                 {"dense_eq": "equality", "dense_ham2": "Hamming", "dense_lev2": "Levenshtein <= 2"}[probe["case"]])
-        out[key] = {"kernel": kernel, "hbm_bytes_per_tile": total / tiles, "tiles_measured": tiles,
+        out[key] = {"kernel": kernel, "unit": probe.get("unit"), "unit_id": probe.get("unit_id"),
+                    "build_id": probe.get("build_id"),
+                    "hbm_bytes_per_tile": total / tiles, "tiles_measured": tiles,
                     "kernel_us_per_scan": round(dur, 1), "algorithmic_bytes_per_tile": probe["algorithmic_bytes"] / tiles,
                     "kernels": {k: round(v["hbm_bytes_per_dispatch"]) for k, v in sorted(kernels.items())},
                     "source": os.path.relpath(path, REPO)}

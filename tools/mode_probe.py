@@ -99,7 +99,11 @@ def main():
                  "window_groups": sc.get_option("dense_window_groups"),
                  "window_dwords": sc.get_option("dense_window_dwords")}
     case_name = ("novaseq_" + a.case) if a.workload == "novaseq" else a.case
-    print(json.dumps({**extra, "kernel": sc.last_kernel(), "case": case_name, "workload": "dense" if a.case in DENSE else a.workload, "tiles": tiles,
+    from well_duplicates_amd import _lib
+    ids = _lib.build_ids()
+    print(json.dumps({**extra, "kernel": sc.last_kernel(), "build_id": ids["all"],
+                      "unit": _lib.unit_of_kernel(sc.last_kernel()), "unit_id": ids.get(_lib.unit_of_kernel(sc.last_kernel())),
+                      "case": case_name, "workload": "dense" if a.case in DENSE else a.workload, "tiles": tiles,
                       "T": T, "levels": levels, "L": L, "mode": mode, "k": k, "plant_per_64k": spec.plant_per_64k,
                       "scans_timed": cnt, "kernel_ms": round(ms, 5), "compares": C, "valid_targets": Tv,
                       "duplicates": int(blk[:, 1 + levels:1 + 2 * levels].sum()),

@@ -6,7 +6,7 @@ set -e
 cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/..}"
 export TMPDIR=/tmp
 RAW=/tmp/wd_pmc_raw
-TAG=${TAG:-r03}
+TAG=${TAG:-r04}
 mkdir -p gpurun_out/pmc $RAW
 run() {   # case, extra probe args
   python3 tools/pmc_collect.py --case $1 --tag $TAG --out $RAW ${2:+--probe-args "$2"} > gpurun_out/pmc_$1_$3.log 2>&1 || true
@@ -21,4 +21,6 @@ for what in ${@:-sparse novaseq dense}; do
 done
 cp $RAW/*.json gpurun_out/pmc/
 find $RAW -name "*kernel_stats.csv" | while read f; do cp "$f" gpurun_out/pmc/$(echo "$f" | sed "s|$RAW/||; s|/|_|g"); done
+# the resource table of the very library the counters were read from (its build ids inside)
+python3 tools/kernel_resources.py --json gpurun_out/pmc/${TAG}_kernel_resources.json > gpurun_out/pmc/${TAG}_kernel_resources.txt
 ls gpurun_out/pmc

@@ -96,6 +96,11 @@ def main():
         for line in res.stdout.splitlines():
             if line.startswith("{") and '"case"' in line:
                 summary["probe"][p] = json.loads(line)
+                # every pass must have profiled the same code: the library's own hashes (wd_build_id)
+                for key in ("build_id", "unit", "unit_id", "kernel"):
+                    v = summary["probe"][p].get(key)
+                    if summary.setdefault(key, v) != v:
+                        raise SystemExit("pass %s ran %s = %s, an earlier pass %s" % (p, key, v, summary[key]))
         if PASSES[p] is None:
             for f in glob.glob(os.path.join(d, "**", "*kernel_trace.csv"), recursive=True):
                 summarise_trace(f, summary["kernels"])

@@ -134,12 +134,56 @@ def source_build_id() -> str:
     return h.hexdigest()[:16]
 
 
+def source_unit_ids() -> dict:
+    """{unit: sha256[:16] of csrc/welldup_<unit>.hip and everything it includes}: the per-unit part of
+    `wd_build_id()`.  A kernel's counter evidence is keyed by the unit it lives in (`unit_of_kernel`)."""
+    import hashlib
+    out = {}
+    for u in UNITS:
+        h = hashlib.sha256()
+        for f in sorted(_deps(os.path.join(CSRC, "welldup_%s.hip" % u))):
+            h.update(os.path.basename(f).encode() + b"\0")
+            with open(f, "rb") as fh:
+                h.update(fh.read())
+        out[u] = h.hexdigest()[:16]
+    return out
+
+
+def parse_build_id(text: str) -> dict:
+    """'<all> core=<id> scan=<id> ...' -> {"all": ..., "core": ..., ...}"""
+    parts = text.split()
+    out = {"all": parts[0] if parts else "unknown"}
+    for p in parts[1:]:
+        k, _, v = p.partition("=")
+        out[k] = v
+    return out
+
+
+def build_ids() -> dict:
+    """The loaded library's own account of the sources it was built from (wd_build_id)."""
+    return parse_build_id(load().wd_build_id().decode())
+
+
+def unit_of_kernel(kernel: str) -> str:
+    """Translation unit a compare kernel (as wd_last_kernel names it) is compiled in."""
+    if kernel.startswith("k_scan_q"):
+        return "queue"
+    if kernel.startswith("k_scan_lines"):
+        return "lines"
+    if kernel.startswith(("dense chain", "k_dense")):
+        return "dense"
+    if kernel.startswith(("k_inflate", "k_cbcl", "k_gather", "k_interleave", "k_scatter")):
+        return "ingest"
+    return "scan"
+
+
 def build(force: bool = False, verbose: bool = False, jobs: int = 0) -> str:
     """Compile csrc/welldup_*.hip for gfx950 (one object per unit, in parallel, only the units whose
     sources changed) and link them into the package directory."""
     import concurrent.futures
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     bid = source_build_id()
+    uids = source_unit_ids()
     os.makedirs(OBJ_DIR, exist_ok=True)
     stamp = os.path.join(OBJ_DIR, "build_id")
     stale_id = not os.path.exists(stamp) or open(stamp).read().strip() != bid
@@ -158,7 +202,9 @@ def build(force: bool = False, verbose: bool = False, jobs: int = 0) -> str:
     def compile_one(job):
         u, src, obj = job
         cmd = [hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-I" + INCLUDE,
-               '-DWD_BUILD_ID="%s"' % bid, "-c", src, "-o", obj]
+               '-DWD_UNIT_ID="%s"' % uids[u], "-c", src, "-o", obj]
+        if u == "core":
+            cmd.insert(-4, '-DWD_BUILD_ID="%s"' % bid)
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)

@@ -223,6 +223,13 @@ struct wd_ctx {
 
 namespace wd {
 
+// one per translation unit: the hash of the sources it was compiled from (wd_build_id lists them)
+const char *unit_id_scan();
+const char *unit_id_queue();
+const char *unit_id_lines();
+const char *unit_id_dense();
+const char *unit_id_ingest();
+
 // welldup_core.hip
 int fail(wd_ctx *ctx, int code, const std::string &msg);
 int bind_device(wd_ctx *ctx);

@@ -101,7 +101,19 @@ int wd_version(void) { return 100; }
 #ifndef WD_BUILD_ID
 #define WD_BUILD_ID "unknown"
 #endif
-const char *wd_build_id(void) { return WD_BUILD_ID; }
+#ifndef WD_UNIT_ID
+#define WD_UNIT_ID "unknown"
+#endif
+const char *wd_build_id(void)
+{
+    // "<all sources> core=<..> scan=<..> queue=<..> lines=<..> dense=<..> ingest=<..>": the whole tree's hash,
+    // then one per translation unit (its .hip and everything it includes), so that evidence about a kernel
+    // goes stale when ITS code changes and not when a comment in the ingest does
+    static const std::string id = std::string(WD_BUILD_ID) + " core=" + WD_UNIT_ID + " scan=" + unit_id_scan() +
+                                  " queue=" + unit_id_queue() + " lines=" + unit_id_lines() +
+                                  " dense=" + unit_id_dense() + " ingest=" + unit_id_ingest();
+    return id.c_str();
+}
 
 const char *wd_strerror(int code)
 {

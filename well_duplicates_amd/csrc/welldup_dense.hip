@@ -2,6 +2,11 @@
 // the chain of k_dense_* kernels (scan_dense.inc).  Called from wd_scan_async (welldup_scan.hip).
 #include "wd_ctx.h"
 
+#ifndef WD_UNIT_ID
+#define WD_UNIT_ID "unknown"
+#endif
+namespace wd { const char *unit_id_dense() { return WD_UNIT_ID; } }      // hash of this unit's sources (wd_build_id)
+
 namespace {
 
 #include "device_common.inc"

@@ -4,6 +4,11 @@
 // :255-325, :333-345).
 #include "wd_ctx.h"
 
+#ifndef WD_UNIT_ID
+#define WD_UNIT_ID "unknown"
+#endif
+namespace wd { const char *unit_id_ingest() { return WD_UNIT_ID; } }      // hash of this unit's sources (wd_build_id)
+
 using namespace wd;
 
 // (at global scope: completes InfJob / InfResult, which the context points to)

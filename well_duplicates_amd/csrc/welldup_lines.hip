@@ -2,6 +2,11 @@
 // sampled targets with large neighbourhoods (BASELINE configs[3]); called from wd_scan_async.
 #include "wd_ctx.h"
 
+#ifndef WD_UNIT_ID
+#define WD_UNIT_ID "unknown"
+#endif
+namespace wd { const char *unit_id_lines() { return WD_UNIT_ID; } }      // hash of this unit's sources (wd_build_id)
+
 using namespace wd;
 
 namespace {

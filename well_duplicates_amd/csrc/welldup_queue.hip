@@ -3,6 +3,11 @@
 // the queue entries; plane-per-cycle and interleaved-by-four input.  Called from wd_scan_async.
 #include "wd_ctx.h"
 
+#ifndef WD_UNIT_ID
+#define WD_UNIT_ID "unknown"
+#endif
+namespace wd { const char *unit_id_queue() { return WD_UNIT_ID; } }      // hash of this unit's sources (wd_build_id)
+
 using namespace wd;
 
 namespace {

@@ -13,6 +13,11 @@
 // no dual paths: gfx950 HIP only.
 #include "wd_ctx.h"
 
+#ifndef WD_UNIT_ID
+#define WD_UNIT_ID "unknown"
+#endif
+namespace wd { const char *unit_id_scan() { return WD_UNIT_ID; } }      // hash of this unit's sources (wd_build_id)
+
 using namespace wd;
 
 namespace {
