@@ -307,6 +307,39 @@ def novaseq_probe(device, n_tiles, levels=7, targets=10000, bases=50):
                  "algorithmic_bytes": b_alg,
                  "alg_bytes_over_peak": round(b_alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
                 "novaseq_%s_T%d_l%d_L%d" % (case, T, levels, bases), n_tiles, ms, sc.last_kernel())
+        # the same tiles with their cycles interleaved by four: the line walk reads a dword per pair and round
+        # (k_scan_lines<.., 4>), a line of 32 wells x 4 cycles once per group instead of 128 wells once per cycle
+        try:
+            il = TileBatch(sc, n_tiles, bases, n, interleave=4)
+            il.fill_synthetic(spec, [(1, int(t)) for t in tile_ids], list(range(bases)))
+            out2 = sc.malloc(n_tiles * ncnt * 8)
+            res["interleaved_by_4"] = {}
+            for name, mode, k, case in (("equality", MODE_EQ, 0, "il"), ("levenshtein_k2", MODE_LEVENSHTEIN, 2, "il_lev2")):
+                sc.set_option("well_stride", 4)
+                sc.scan_async(il.tables, n_tiles, bases, n, mode, k, out2)
+                sc.profile_reset()
+                for _ in range(5):
+                    sc.scan_async(il.tables, n_tiles, bases, n, mode, k, out2)
+                ms, launches = sc.profile_get()
+                kern = sc.last_kernel()
+                sc.set_option("well_stride", 1)
+                ms /= max(1, launches)
+                sc.scan_async(tb.tables, n_tiles, bases, n, mode, k, out)          # the plane layout's counters, to compare
+                sc.scan_status()
+                blk = sc.d2h(out, n_tiles * ncnt * 8, np.int64).reshape(n_tiles, ncnt)
+                blk2 = sc.d2h(out2, n_tiles * ncnt * 8, np.int64).reshape(n_tiles, ncnt)
+                C, Tv = int(blk2[:, 1:1 + levels].sum()), int(blk2[:, 0].sum())
+                b_alg = C * (bases + 4) + Tv * (bases + 5) + 8 * ncnt * n_tiles
+                res["interleaved_by_4"][name] = with_traffic(
+                    {"kernel_ms": round(ms, 4), "compares_per_s": round(C / (ms * 1e-3), 1),
+                     "alg_bytes_over_peak": round(b_alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                     "same_counters_as_plane_layout": bool((blk == blk2).all())},
+                    "novaseq_%s_T%d_l%d_L%d" % (case, T, levels, bases), n_tiles, ms, kern)
+            sc.free(out2)
+            il.free()
+        except Exception as e:          # noqa: BLE001 - a measurement, not the scan
+            sc.set_option("well_stride", 1)
+            res["interleaved_by_4"] = {"error": repr(e)}
         # the .cbcl side of this config: 8 tiles x `bases` cycles as NovaSeq writes them (one file per
         # cycle and surface, one gzip block per tile: 2 wells per byte, 2 quality bits, excluded wells
         # left out), through the GPU decoder (wd_load_cbcl_batch) and through the host loader
@@ -460,7 +493,7 @@ def e2e_probe(device, n_tiles, rows, cols, centre, lvl_off, nbr, cycles=50, thre
         serial, text_s = min(run(["--serial-ingest"]) for _ in range(2))
         run(["--host-inflate"])
         host, text_h = min(run(["--host-inflate"]) for _ in range(2))
-        inter, text_i = min(run(["--layout", "interleaved"]) for _ in range(2))
+        inter, text_i = min(run(["--layout", "planes"]) for _ in range(2))       # (the default is --layout auto = interleaved here)
         # ... and as the reference runs by default: with the three stderr lines per duplicate (:260-262)
         import contextlib
         argv_log = [a for a in argv if a != "-q"]
@@ -520,7 +553,8 @@ def e2e_probe(device, n_tiles, rows, cols, centre, lvl_off, nbr, cycles=50, thre
                 "host_inflate_seconds": round(host, 4),
                 "gpu_inflate_gain": round(host / best, 3) if best > 0 else None,
                 "ingest_only": ingest,
-                "interleaved_layout_seconds": round(inter, 4),
+                "resident_layout": "interleaved by four (--layout auto: -e 2 on sampled targets of a .bcl.gz run)",
+                "planes_layout_seconds": round(inter, 4),
                 "with_duplicate_log_seconds": round(logged, 4), "duplicates_logged": dup_lines,
                 "same_report": text == text_s == text_i == text_h == text_l, "run_dir_write_s": round(write_s, 1),
                 "reference_s_per_tile": 7.9,
@@ -829,6 +863,12 @@ def main(argv=None):
                  "alg_bytes_over_peak": round(b_il / (l_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
                 "il_lev2_T%d_l%d_L%d" % (T, levels, L), n_il, l_ms, il_kernel)
             il.free()
+            # what a run of the CLI keeps resident and scans (--layout auto: count_well_duplicates.py of this
+            # package, resident_layout): the interleaved layout for the reference's default metric
+            other["cli_default_path"] = {
+                "layout": "interleaved_by_4 (--layout auto: sampled targets, -e <= 3 or --hamming, .bcl.gz runs)",
+                "levenshtein_k2": dict(other["interleaved_by_4"]["levenshtein_k2"]),
+                "planes_levenshtein_k2_kernel_ms": other.get("levenshtein_k2", {}).get("kernel_ms")}
         # the lazy gather's worst input: every read equal (amplicons, failed cycles - here all no-calls),
         # so that no neighbour ever dies early; 8 tiles, the headline's targets, both layouts
         if rank == 0 and world == 1 and args.interleaved_tiles > 0:

@@ -835,16 +835,36 @@ def test_interleaved_layout_equals_plane_layout(sc, L):
         inter.fill_synthetic(spec, tiles, list(range(L)))
         for c in range(L):
             assert (inter.download_plane(1, c) == plane.download_plane(1, c)).all()
+        host = [compact_tile(spec, lane, tile, list(range(L)), centre, nbr) for lane, tile in tiles]
         for mode, k in ((0, 0), (1, 1), (1, 2), (1, 3), (1, L), (2, 1), (2, 2), (2, 3)):
+            sc.set_option("line_walk", 0)
             sc.hitlog_enable(100000)
             want = plane.count(mode, k, per_target=True)
             want_hits, want_total = sc.hitlog_fetch(100000)
-            got = inter.count(mode, k, per_target=True)
-            hits, total = sc.hitlog_fetch(100000)
+            for i, (planes, filt, c2, n2, _) in enumerate(host):          # the plane layout against the oracle
+                valid, dups, lens, _ = oracle.count_tile(planes, filt, c2, lvl_off, n2, mode, k)
+                ref = want[1][i].astype(np.int64)
+                ref[ref == INVALID_TARGET] = -1
+                assert (ref == np.where(valid[:, None] == 1, dups, -1)).all(), (L, mode, k, i)
+            # the interleaved batch: target by target (k_scan_q<.., 4>) and pair by pair in the order of the
+            # neighbour wells (k_scan_lines<.., 4>: one dword per pair and round, two for Levenshtein <= 2)
+            for walk in (0, 1):
+                sc.set_option("line_walk", walk)
+                sc.set_option("line_pairs", 900 if walk else 0)
+                got = inter.count(mode, k, per_target=True)
+                hits, total = sc.hitlog_fetch(100000)
+                assert (got[0] == want[0]).all() and (got[1] == want[1]).all(), (L, mode, k, walk)
+                key = lambda h: (int(h["tile"]), int(h["target"]), int(h["slot"]), int(h["dist"]))
+                assert total == want_total and sorted(map(key, hits)) == sorted(map(key, want_hits)), (L, mode, k, walk)
+                ran = sc.last_kernel()
+                lev = mode == 2 and k >= 2 and L >= 2       # (k >= L is a Hamming problem, but the hit log wants true distances)
+                if walk and (not lev or k == 2):
+                    assert ran.startswith("k_scan_lines<true, 8, -1, 4>" if lev else "k_scan_lines<true, 4, 0, 4>"), (mode, k, ran)
+                else:
+                    assert ran.startswith("k_scan_q<true") and ran.split(">")[0].endswith(", 4"), (mode, k, walk, ran)
             sc.hitlog_enable(0)
-            assert (got[0] == want[0]).all() and (got[1] == want[1]).all(), (L, mode, k)
-            key = lambda h: (int(h["tile"]), int(h["target"]), int(h["slot"]), int(h["dist"]))
-            assert total == want_total and sorted(map(key, hits)) == sorted(map(key, want_hits))
+        sc.set_option("line_walk", -1)
+        sc.set_option("line_pairs", 0)
         if L >= 5:
             with pytest.raises(RuntimeError):                 # wider bands read planes only
                 inter.count(2, 4)
@@ -863,7 +883,10 @@ def test_interleaved_layout_equals_plane_layout(sc, L):
             finally:
                 sc.set_option("well_stride", 1)
     finally:
+        sc.hitlog_enable(0)
         sc.set_option("dense_kernel", -1)
+        sc.set_option("line_walk", -1)
+        sc.set_option("line_pairs", 0)
         plane.free()
         inter.free()
 

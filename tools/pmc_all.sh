@@ -15,7 +15,7 @@ run() {   # case, extra probe args
 for what in ${@:-sparse novaseq dense}; do
   case $what in
     sparse)  for c in eq ham2 lev2 il il_lev2; do run $c "" sparse; done ;;
-    novaseq) for c in eq lev2; do run $c "--workload novaseq" novaseq; done ;;
+    novaseq) for c in eq lev2 il il_lev2; do run $c "--workload novaseq" novaseq; done ;;
     dense)   for c in dense_eq dense_ham2 dense_lev2; do run $c "--tiles 8" dense; done ;;
   esac
 done

@@ -21,7 +21,9 @@ Differences from the reference, all deliberate:
   * `-t` with a pattern that matches nothing raises the AssertionError the reference
     intends (its own message formatting raises NameError first);
   * extra flags: --device, --dist-backend, --tile-batch, --threads, --strict, -o/--output,
-    --all-wells, --slocs, --layout, --serial-ingest.
+    --all-wells, --slocs, --layout, --serial-ingest;
+  * the resident layout is chosen per run (--layout auto): sampled scans the interleaved-by-four layout
+    serves (the reference's default -e 2 among them) keep their cycles interleaved, everything else planes.
 """
 from __future__ import annotations
 
@@ -102,11 +104,12 @@ def parse_args(argv=None):
                         "prepare_cluster_indexes.py; the per-duplicate log is not written in this mode")
     p.add_argument("--slocs", default=None,
                    help="s.locs file for --all-wells (default: <run>/Data/Intensities/s.locs)")
-    p.add_argument("--layout", default="planes", choices=["planes", "interleaved"],
+    p.add_argument("--layout", default="auto", choices=["auto", "planes", "interleaved"],
                    help="how the scanned cycles sit in GPU memory: planes = one plane per cycle, as in the "
                         ".bcl.gz files; interleaved = the four cycles of a group side by side per well (the "
                         "loaders write it at no extra cost; the scan of sampled targets then touches half the "
-                        "cache lines).  interleaved: .bcl.gz runs, -e <= 3, not with --all-wells")
+                        "cache lines).  interleaved: .bcl.gz runs, -e <= 3 (any -e with --hamming up to 254), not "
+                        "with --all-wells.  auto (default) = interleaved wherever that holds, else planes")
     p.add_argument("--host-inflate", action="store_true",
                    help="gunzip the .bcl.gz files on the host threads (the default inflates them on the GPU: "
                         "the threads only read the compressed files, one wave per file decodes it; files the "
@@ -138,6 +141,28 @@ def default_threads() -> int:
         pass
     local_world = max(1, int(os.environ.get("LOCAL_WORLD_SIZE", "1") or 1))
     return max(1, min(32, cpus // local_world))
+
+
+def resident_layout(args, mode, k, csr, reader, lanes, tiles, cycle_list) -> int:
+    """--layout -> the well stride of the batches (1 = a plane per cycle, 4 = interleaved by four).  `auto`
+    takes the interleaved layout wherever the kernels that read it serve the run: sampled targets of at most
+    508 neighbour slots, equality / Hamming <= 254 / Levenshtein <= 3 (the reference's default is 2:
+    count_well_duplicates.py:282-283), .bcl.gz files (a NovaSeq run's .cbcl blocks are expanded into planes)."""
+    from .scanner import MODE_EQ, MODE_HAMMING
+    if args.layout != "auto":
+        return 4 if args.layout == "interleaved" else 1
+    if args.all_wells or csr is None:
+        return 1
+    served = mode == MODE_EQ or (mode == MODE_HAMMING and k <= 254) or (mode not in (MODE_EQ, MODE_HAMMING) and k <= 3)
+    lvl_off = csr[1]
+    slots = int((lvl_off[:, -1] - lvl_off[:, 0]).max()) if lvl_off.shape[0] else 0
+    if not served or slots > 508 or not cycle_list:
+        return 1
+    try:                                    # (whatever is wrong with the first tile is reported when it is loaded)
+        first = reader.get_tile(list(lanes)[0], tiles[0])
+        return 4 if os.path.exists(first.plane_path(cycle_list[0])) else 1
+    except (OSError, IndexError, RuntimeError, AssertionError):
+        return 1
 
 
 def _lap(what: str):
@@ -530,7 +555,7 @@ def _main(args, log, wdist, rank, world, device, opener, early):
                                max(0, args.tile_batch), args.threads,
                                0 if (args.quiet or args.all_wells) else len(cycles),
                                overlap=not args.serial_ingest,
-                               interleave=4 if args.layout == "interleaved" else 1,
+                               interleave=resident_layout(args, mode, k, csr, reader, lanes, tiles, cycle_list),
                                gpu_inflate=not args.host_inflate, lane_done=lane_done, into=results)
             except Exception as e:          # noqa: BLE001 - re-raised below, on every rank
                 err = e

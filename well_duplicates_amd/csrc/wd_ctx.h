@@ -173,7 +173,7 @@ struct wd_ctx {
     int32_t *d_lw_well = nullptr;
     uint32_t *d_lw_meta = nullptr, *d_lw_btgt = nullptr;
     int4 *d_lw_blk = nullptr;
-    int32_t *d_lw_bcen = nullptr;
+    int32_t *d_lw_bcen = nullptr, *d_lw_boff = nullptr;
     int lw_blocks = -1;                                // -1: not built for the current targets; 0: does not apply to them
     int lw_tmax = 0;                                   // most targets of any block
     int line_pairs = 0;                                // option: pairs per block of the line walk (0 = kLwPairs)

@@ -45,7 +45,8 @@ void drop_line_tables(wd_ctx *ctx)
     (void)hipFree(ctx->d_lw_btgt);
     (void)hipFree(ctx->d_lw_blk);
     (void)hipFree(ctx->d_lw_bcen);
-    ctx->d_lw_bcen = nullptr;
+    (void)hipFree(ctx->d_lw_boff);
+    ctx->d_lw_bcen = ctx->d_lw_boff = nullptr;
     ctx->d_lw_well = nullptr;
     ctx->d_lw_meta = ctx->d_lw_btgt = nullptr;
     ctx->d_lw_blk = nullptr;
@@ -155,9 +156,12 @@ int build_line_tables(wd_ctx *ctx)
     }
     ctx->lw_tmax = (tmax + 3) & ~3;
     // (a target without a single pair would never be counted: has_empty_level excludes it)
-    std::vector<int32_t> bcen(btgt.size());
-    for (size_t i = 0; i < btgt.size(); i++)
-        bcen[i] = cen[(size_t)(btgt[i] & 0x7FFFFFFFu)];
+    std::vector<int32_t> bcen(btgt.size()), boff(btgt.size() * row);
+    for (size_t i = 0; i < btgt.size(); i++) {
+        const size_t t = (size_t)(btgt[i] & 0x7FFFFFFFu);
+        bcen[i] = cen[t];
+        memcpy(&boff[i * row], &off[t * row], row * sizeof(int32_t));
+    }
     // all five tables or none: a failure half way frees what it has
     auto upload = [&](auto *&dst, const void *src, size_t bytes) -> hipError_t {
         hipError_t e = hipMalloc((void **)&dst, bytes);
@@ -168,6 +172,7 @@ int build_line_tables(wd_ctx *ctx)
     WD_LW_HIP(upload(ctx->d_lw_btgt, btgt.data(), btgt.size() * sizeof(uint32_t)));
     WD_LW_HIP(upload(ctx->d_lw_blk, blk.data(), blk.size() * sizeof(int4)));
     WD_LW_HIP(upload(ctx->d_lw_bcen, bcen.data(), bcen.size() * sizeof(int32_t)));
+    WD_LW_HIP(upload(ctx->d_lw_boff, boff.data(), boff.size() * sizeof(int32_t)));
 #undef WD_LW_HIP
     ctx->lw_blocks = (int)blk.size();
     return WD_OK;
@@ -185,6 +190,7 @@ int launch_lines_t(wd_ctx *ctx, const ScanArgs &sa, int n_tiles, bool lev2, int 
     a.blk = ctx->d_lw_blk;
     a.btgt = ctx->d_lw_btgt;
     a.bcen = ctx->d_lw_bcen;
+    a.boff = ctx->d_lw_boff;
     a.n_blk = ctx->lw_blocks;
     a.tmax = ctx->lw_tmax;
     a.mask_stride = (((long long)sa.T + 3) / 4 + 31) & ~31ll;
@@ -205,6 +211,18 @@ int launch_lines_t(wd_ctx *ctx, const ScanArgs &sa, int n_tiles, bool lev2, int 
                  (int)(B1_), (int)(LEVH_));                                                              \
         hipLaunchKernelGGL((k_scan_lines<STRIDED, (B1_), (LEVH_)>), grid, dim3(kBlock), lds, ctx->stream, a); \
     } while (0)
+    if constexpr (STRIDED) {
+        if (ctx->well_stride == 4) {        // interleaved: the first round is one dword per pair, two for Levenshtein <= 2
+            if (lev2) {
+                snprintf(ctx->last_kernel, sizeof(ctx->last_kernel), "k_scan_lines<true, 8, %d, 4>", kLev2Closed);
+                hipLaunchKernelGGL((k_scan_lines<true, 8, kLev2Closed, 4>), grid, dim3(kBlock), lds, ctx->stream, a);
+            } else {
+                snprintf(ctx->last_kernel, sizeof(ctx->last_kernel), "k_scan_lines<true, 4, 0, 4>");
+                hipLaunchKernelGGL((k_scan_lines<true, 4, 0, 4>), grid, dim3(kBlock), lds, ctx->stream, a);
+            }
+            return WD_OK;
+        }
+    }
     if (lev2) {
         WD_LAUNCH_L(5, kLev2Closed);
     } else {

@@ -399,20 +399,21 @@ try {
     // Levenshtein <= 2 / <= 3 in the queue kernel (band half-width 1) reads the interleaved layout too
     const bool lev_queue_il = lev && !lev_generic && kk / 2 == 1 && ctx->queue_kernel && ctx->early_exit &&
                               ctx->k_max <= (int64_t)kMaxPasses * kPass;
-    if (ws == 4 && (use_dense || !strided || !(use_queue || lev_queue_il)))
-        return fail(ctx, WD_ERR_UNSUPPORTED,
-                    "the interleaved layout is read by the queue kernel only (equality, Hamming, Levenshtein <= 3)");
 
     // the line walk (scan_lines.inc): the pairs in the order of their neighbour wells, where the queue kernel
     // would run (planes, early exit, equality / Hamming, or Levenshtein <= 2 by the closed form)
     bool use_lines = false;
-    if (line_walk_wanted(ctx) && !use_dense && ws == 1 && ctx->queue_kernel && ctx->early_exit && L >= 1 && levels <= 8 &&
+    if (line_walk_wanted(ctx) && !use_dense && (ws == 1 || strided) && ctx->queue_kernel && ctx->early_exit && L >= 1 && levels <= 8 &&
         ((!lev && kk <= 254) || (lev && kk == 2 && ctx->lev2_closed && !lev_generic))) {
         // (targets of more slots than the queue kernel's four passes hold, up to 4095, are the walk's too)
         if (int rc = build_line_tables(ctx))
             return rc;
         use_lines = ctx->lw_blocks > 0;
     }
+    if (ws == 4 && (use_dense || !strided || !(use_lines || use_queue || lev_queue_il)))
+        return fail(ctx, WD_ERR_UNSUPPORTED,
+                    "the interleaved layout is read by the queue kernel and the line walk only (equality, Hamming, "
+                    "Levenshtein <= 3)");
 
     std::pair<hipEvent_t, hipEvent_t> ev{nullptr, nullptr};
     const bool timed = ctx->profile > 0 && (ctx->profile_seq++ % ctx->profile) == 0;
