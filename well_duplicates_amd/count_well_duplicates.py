@@ -282,6 +282,10 @@ def scan_lanes(sc: Scanner, reader, lane_tiles, cycle_list, mode, k, csr, wells,
                 sc.load_bcl_gz(handles[i].plane_path(cycle_list[c]), tb.plane_ptr(i, c), n_clusters, interleave)
             except FileNotFoundError:       # only a missing file: a corrupt one is reported as such
                 if interleave != 1:
+                    # (a .bcl.gz run with a file missing is the reference's FileNotFoundError,
+                    # bcl_direct_reader.py:207-216; only a .cbcl run is a matter of the layout)
+                    if not os.path.exists(handles[i].cbcl_path(cycle_list[c])):
+                        raise
                     raise RuntimeError("--layout interleaved reads .bcl.gz runs only") from None
                 if filt:
                     filt[i].result()
