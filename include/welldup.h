@@ -280,6 +280,10 @@ int wd_gunzip(const uint8_t *src, size_t src_len, uint8_t *dst, size_t dst_cap, 
  * wd_load_bcl_gz. */
 int wd_load_cbcl_tile(wd_ctx *ctx, const char *path, int tile_number, const uint8_t *filter_dev,
                       int64_t n_clusters, uint8_t *dst_dev);
+/* The same into the interleaved layout: well_stride = 4, dst_dev = group base + cycle % 4 (as
+ * wd_load_bcl_gz_strided); 1 = wd_load_cbcl_tile. */
+int wd_load_cbcl_tile_strided(wd_ctx *ctx, const char *path, int tile_number, const uint8_t *filter_dev,
+                              int64_t n_clusters, uint8_t *dst_dev, int well_stride);
 /* A batch of tile blocks, inflated on the GPU: entry i = the block of tile tile_number[i] in the .cbcl
  * file paths[i] -> dst_dev[i], as n calls of wd_load_cbcl_tile would (bcl_direct_reader.py:255-325;
  * filter_dev[i] must already hold the tile's filter bytes).  The files' headers and tile tables are
@@ -291,6 +295,12 @@ int wd_load_cbcl_tile(wd_ctx *ctx, const char *path, int tile_number, const uint
 int wd_load_cbcl_batch(wd_ctx *ctx, int n, const char *const *paths, const int *tile_number,
                        const uint8_t *const *filter_dev, uint8_t *const *dst_dev, int64_t n_clusters, int threads,
                        int *rc);
+/* ... with every expanded plane landing in its byte lane of an interleaved group (well_stride = 4, dst_dev[i] =
+ * group base + cycle % 4), so that a NovaSeq run can be kept resident in the layout the sampled scans read in
+ * half the cache lines; well_stride = 1: wd_load_cbcl_batch. */
+int wd_load_cbcl_batch_strided(wd_ctx *ctx, int n, const char *const *paths, const int *tile_number,
+                               const uint8_t *const *filter_dev, uint8_t *const *dst_dev, int64_t n_clusters,
+                               int well_stride, int threads, int *rc);
 int wd_gather_wells(wd_ctx *ctx, const uint8_t *const *planes, int L, const int32_t *idx, int64_t n,
                     int64_t n_clusters, uint8_t *out_host);
 

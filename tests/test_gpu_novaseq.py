@@ -106,5 +106,25 @@ def test_config4_full_size(sc, run_dir):
                 sc.set_option("early_exit", 1)
                 sc.set_option("targets_per_block", 64)
                 sc.set_option("dense_kernel", -1)
+        # the resident layout the CLI keeps for this configuration (--layout auto): the .cbcl blocks expanded
+        # straight into their byte lanes of the interleaved groups - tile 0 block by block
+        # (wd_load_cbcl_tile_strided), tile 1 through the GPU decoder (wd_load_cbcl_batch_strided) - and
+        # scanned by the line walk a dword at a time (k_scan_lines<.., 4>)
+        il = TileBatch(sc, len(TILES), L, N, interleave=4)
+        try:
+            for i, h in enumerate(handles):
+                sc.load_filter(h.filter_file, il.filter_ptr(i), N)
+            for c in range(L):
+                sc.load_cbcl_tile(handles[0].cbcl_path(c), int(handles[0].tile), il.filter_ptr(0), N, il.plane_ptr(0, c), 4)
+            sc.load_cbcl_batch([(handles[1].cbcl_path(c), int(handles[1].tile), il.filter_ptr(1), il.plane_ptr(1, c))
+                                for c in range(L)], N, threads=4, well_stride=4)
+            for i, c in ((0, 0), (0, 5), (1, 2), (1, L - 1)):
+                assert (il.download_plane(i, c) == tb.download_plane(i, c)).all(), (i, c)
+            for key in ((0, 0), (1, 2), (2, 2)):
+                blocks, pt = il.count(key[0], key[1], per_target=True)
+                assert sc.last_kernel().startswith("k_scan_lines<true, 8, -1, 4>" if key[0] == 2 else "k_scan_lines<true, 4, 0, 4>")
+                assert (blocks == results[key][0]).all() and (pt == results[key][1]).all(), key
+        finally:
+            il.free()
     finally:
         tb.free()

@@ -79,6 +79,9 @@ PROTOTYPES = {
     "wd_load_cbcl_tile": (_i, [_vp, ctypes.c_char_p, _i, _vp, _i64, _vp]),
     "wd_load_cbcl_batch": (_i, [_vp, _i, ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(_i), _pp, _pp, _i64, _i,
                                 ctypes.POINTER(_i)]),
+    "wd_load_cbcl_tile_strided": (_i, [_vp, ctypes.c_char_p, _i, _vp, _i64, _vp, _i]),
+    "wd_load_cbcl_batch_strided": (_i, [_vp, _i, ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(_i), _pp, _pp, _i64, _i, _i,
+                                        ctypes.POINTER(_i)]),
     "wd_interleave4": (_i, [_vp, ctypes.POINTER(ctypes.c_void_p), _i64, _vp]),
     "wd_gunzip": (_i, [_vp, ctypes.c_size_t, _vp, ctypes.c_size_t, ctypes.POINTER(ctypes.c_size_t), _i]),
     "wd_gather_wells": (_i, [_vp, _pp, _i, _vp, _i64, _i64, _vp]),

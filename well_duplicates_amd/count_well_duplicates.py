@@ -108,7 +108,7 @@ def parse_args(argv=None):
                    help="how the scanned cycles sit in GPU memory: planes = one plane per cycle, as in the "
                         ".bcl.gz files; interleaved = the four cycles of a group side by side per well (the "
                         "loaders write it at no extra cost; the scan of sampled targets then touches half the "
-                        "cache lines).  interleaved: .bcl.gz runs, -e <= 3 (any -e with --hamming up to 254), not "
+                        "cache lines).  interleaved: -e <= 3 (any -e with --hamming up to 254), not "
                         "with --all-wells.  auto (default) = interleaved wherever that holds, else planes")
     p.add_argument("--host-inflate", action="store_true",
                    help="gunzip the .bcl.gz files on the host threads (the default inflates them on the GPU: "
@@ -147,7 +147,8 @@ def resident_layout(args, mode, k, csr, reader, lanes, tiles, cycle_list) -> int
     """--layout -> the well stride of the batches (1 = a plane per cycle, 4 = interleaved by four).  `auto`
     takes the interleaved layout wherever the kernels that read it serve the run: sampled targets of at most
     508 neighbour slots, equality / Hamming <= 254 / Levenshtein <= 3 (the reference's default is 2:
-    count_well_duplicates.py:282-283), .bcl.gz files (a NovaSeq run's .cbcl blocks are expanded into planes)."""
+    count_well_duplicates.py:282-283); .bcl.gz files and the .cbcl blocks of a NovaSeq run are both written
+    straight into it by the loaders."""
     from .scanner import MODE_EQ, MODE_HAMMING
     if args.layout != "auto":
         return 4 if args.layout == "interleaved" else 1
@@ -156,13 +157,9 @@ def resident_layout(args, mode, k, csr, reader, lanes, tiles, cycle_list) -> int
     served = mode == MODE_EQ or (mode == MODE_HAMMING and k <= 254) or (mode not in (MODE_EQ, MODE_HAMMING) and k <= 3)
     lvl_off = csr[1]
     slots = int((lvl_off[:, -1] - lvl_off[:, 0]).max()) if lvl_off.shape[0] else 0
-    if not served or slots > 508 or not cycle_list:
+    if not served or slots > 508 or not cycle_list or lvl_off.shape[0] >= 65536:      # (65536 targets: the dense path, on planes)
         return 1
-    try:                                    # (whatever is wrong with the first tile is reported when it is loaded)
-        first = reader.get_tile(list(lanes)[0], tiles[0])
-        return 4 if os.path.exists(first.plane_path(cycle_list[0])) else 1
-    except (OSError, IndexError, RuntimeError, AssertionError):
-        return 1
+    return 4
 
 
 def _lap(what: str):
@@ -271,7 +268,7 @@ def scan_lanes(sc: Scanner, reader, lane_tiles, cycle_list, mode, k, csr, wells,
         if gpu_inflate and jobs:
             if os.path.exists(handles[0].plane_path(cycle_list[0])):
                 batch = "bcl.gz"
-            elif interleave == 1 and os.path.exists(handles[0].cbcl_path(cycle_list[0])):
+            elif os.path.exists(handles[0].cbcl_path(cycle_list[0])):
                 batch = "cbcl"
         # (in a batch the filters travel with the planes, below)
         filt = [] if batch else [pool.submit(sc.load_filter, h.filter_file, tb.filter_ptr(i), n_clusters)
@@ -281,16 +278,10 @@ def scan_lanes(sc: Scanner, reader, lane_tiles, cycle_list, mode, k, csr, wells,
             try:
                 sc.load_bcl_gz(handles[i].plane_path(cycle_list[c]), tb.plane_ptr(i, c), n_clusters, interleave)
             except FileNotFoundError:       # only a missing file: a corrupt one is reported as such
-                if interleave != 1:
-                    # (a .bcl.gz run with a file missing is the reference's FileNotFoundError,
-                    # bcl_direct_reader.py:207-216; only a .cbcl run is a matter of the layout)
-                    if not os.path.exists(handles[i].cbcl_path(cycle_list[c])):
-                        raise
-                    raise RuntimeError("--layout interleaved reads .bcl.gz runs only") from None
                 if filt:
                     filt[i].result()
                 sc.load_cbcl_tile(handles[i].cbcl_path(cycle_list[c]), int(handles[i].tile),
-                                  tb.filter_ptr(i), n_clusters, tb.plane_ptr(i, c))
+                                  tb.filter_ptr(i), n_clusters, tb.plane_ptr(i, c), interleave)
         if batch == "cbcl":
             # NovaSeq: the filters first (the expansion of a tile's blocks needs its filter in HBM),
             # then every (tile, cycle) block of the batch through one launch of the GPU decoder
@@ -298,7 +289,8 @@ def scan_lanes(sc: Scanner, reader, lane_tiles, cycle_list, mode, k, csr, wells,
                 sc.load_bcl_gz_batch([], [], n_clusters, threads=max(1, threads),
                                      filters=[(h.filter_file, tb.filter_ptr(i)) for i, h in enumerate(handles)])
                 sc.load_cbcl_batch([(handles[i].cbcl_path(cycle_list[c]), int(handles[i].tile), tb.filter_ptr(i),
-                                     tb.plane_ptr(i, c)) for i, c in jobs], n_clusters, threads=max(1, threads))
+                                     tb.plane_ptr(i, c)) for i, c in jobs], n_clusters, threads=max(1, threads),
+                                   well_stride=interleave)
             planes = [pool.submit(load_all)]
         elif batch:
             # the whole batch - planes and filters - goes through one call: the library's threads read

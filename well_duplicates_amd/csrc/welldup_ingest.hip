@@ -1049,8 +1049,14 @@ try {
 
 int wd_load_cbcl_tile(wd_ctx *ctx, const char *path, int tile_number, const uint8_t *filter_dev,
                       int64_t n_clusters, uint8_t *dst_dev)
+{
+    return wd_load_cbcl_tile_strided(ctx, path, tile_number, filter_dev, n_clusters, dst_dev, 1);
+}
+
+int wd_load_cbcl_tile_strided(wd_ctx *ctx, const char *path, int tile_number, const uint8_t *filter_dev,
+                              int64_t n_clusters, uint8_t *dst_dev, int well_stride)
 try {
-    if (!ctx || !path || !dst_dev || !filter_dev || n_clusters < 0)
+    if (!ctx || !path || !dst_dev || !filter_dev || n_clusters < 0 || (well_stride != 1 && well_stride != 4))
         return WD_ERR_ARG;
     if (hipSetDevice(ctx->device) != hipSuccess)
         return WD_ERR_HIP;
@@ -1142,7 +1148,7 @@ try {
         hipLaunchKernelGGL(k_cbcl_scan, dim3(1), dim3(kBlock), 0, sl->stream, sums, chunks);
     }
     hipLaunchKernelGGL(k_cbcl_expand, dim3(chunks), dim3(kBlock), 0, sl->stream, sl->dev, n_records,
-                       filter_dev, sums, (long long)n_clusters, excluded, dst_dev);
+                       filter_dev, sums, (long long)n_clusters, excluded, dst_dev, well_stride);
     if (hipGetLastError() != hipSuccess || hipStreamSynchronize(sl->stream) != hipSuccess)
         return WD_ERR_HIP;
     // the reference dies with IndexError only if a *requested* well lies beyond the block; a
@@ -1162,24 +1168,31 @@ try {
 // An entry the GPU decoder declines or whose checks fail (CRC-32, length) goes through
 // wd_load_cbcl_tile, whose return code is reported; so do the table checks' failures.
 static int load_cbcl_batch_impl(wd_ctx *ctx, int n, const char *const *paths, const int *tile_number,
-                                const uint8_t *const *filter_dev, uint8_t *const *dst_dev, int64_t n_clusters, int threads,
-                                int *rc_out);
+                                const uint8_t *const *filter_dev, uint8_t *const *dst_dev, int64_t n_clusters, int well_stride,
+                                int threads, int *rc_out);
 
 int wd_load_cbcl_batch(wd_ctx *ctx, int n, const char *const *paths, const int *tile_number,
                        const uint8_t *const *filter_dev, uint8_t *const *dst_dev, int64_t n_clusters, int threads,
                        int *rc_out)
 {
+    return wd_load_cbcl_batch_strided(ctx, n, paths, tile_number, filter_dev, dst_dev, n_clusters, 1, threads, rc_out);
+}
+
+int wd_load_cbcl_batch_strided(wd_ctx *ctx, int n, const char *const *paths, const int *tile_number,
+                               const uint8_t *const *filter_dev, uint8_t *const *dst_dev, int64_t n_clusters,
+                               int well_stride, int threads, int *rc_out)
+{
     return guarded(ctx, [&] {
-        return load_cbcl_batch_impl(ctx, n, paths, tile_number, filter_dev, dst_dev, n_clusters, threads, rc_out);
+        return load_cbcl_batch_impl(ctx, n, paths, tile_number, filter_dev, dst_dev, n_clusters, well_stride, threads, rc_out);
     });
 }
 
 static int load_cbcl_batch_impl(wd_ctx *ctx, int n, const char *const *paths, const int *tile_number,
-                                const uint8_t *const *filter_dev, uint8_t *const *dst_dev, int64_t n_clusters, int threads,
-                                int *rc_out)
+                                const uint8_t *const *filter_dev, uint8_t *const *dst_dev, int64_t n_clusters, int well_stride,
+                                int threads, int *rc_out)
 {
     if (!ctx || n < 0 || (n && (!paths || !tile_number || !filter_dev || !dst_dev)) || n_clusters < 0 ||
-        n_clusters > 0x7FFFFFF0ll)
+        n_clusters > 0x7FFFFFF0ll || (well_stride != 1 && well_stride != 4))
         return WD_ERR_ARG;
     if (hipSetDevice(ctx->device) != hipSuccess)
         return WD_ERR_HIP;
@@ -1430,7 +1443,7 @@ static int load_cbcl_batch_impl(wd_ctx *ctx, int n, const char *const *paths, co
                 hipLaunchKernelGGL(k_cbcl_scan, dim3(1), dim3(kBlock), 0, stream, sums, exp_chunks);
             }
             hipLaunchKernelGGL(k_cbcl_expand, dim3(exp_chunks), dim3(kBlock), 0, stream, packed, (long long)e.usize * 2,
-                               filter_dev[i], sums, (long long)n_clusters, e.excluded, dst_dev[i]);
+                               filter_dev[i], sums, (long long)n_clusters, e.excluded, dst_dev[i], well_stride);
         }
         if (hipGetLastError() != hipSuccess ||
             hipMemcpyAsync(slot.h_res, slot.d_res, sizeof(InfResult) * nj, hipMemcpyDeviceToHost, stream) != hipSuccess)
@@ -1485,7 +1498,8 @@ static int load_cbcl_batch_impl(wd_ctx *ctx, int n, const char *const *paths, co
                 if (k >= todo.size())
                     return;
                 const int i = todo[k];
-                rc[(size_t)i] = wd_load_cbcl_tile(ctx, paths[i], tile_number[i], filter_dev[i], n_clusters, dst_dev[i]);
+                rc[(size_t)i] = wd_load_cbcl_tile_strided(ctx, paths[i], tile_number[i], filter_dev[i], n_clusters, dst_dev[i],
+                                                          well_stride);
             }
         };
         Crew hp;

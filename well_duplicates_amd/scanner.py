@@ -293,14 +293,15 @@ class Scanner:
         if rc != _lib.OK:
             _raise(self._lib, None, rc, path)
 
-    def load_cbcl_tile(self, path: str, tile: int, filter_dev: int, n_clusters: int, dst: int):
-        """One tile's block of a NovaSeq .cbcl file -> byte plane on the device (thread-safe)."""
-        rc = self._lib.wd_load_cbcl_tile(self._ctx, os.fsencode(path), int(tile),
-                                         ctypes.c_void_p(filter_dev), int(n_clusters), ctypes.c_void_p(dst))
+    def load_cbcl_tile(self, path: str, tile: int, filter_dev: int, n_clusters: int, dst: int, well_stride: int = 1):
+        """One tile's block of a NovaSeq .cbcl file -> byte plane on the device (thread-safe); well_stride = 4:
+        into its byte lane of an interleaved group (dst = TileBatch.plane_ptr of an interleaved batch)."""
+        rc = self._lib.wd_load_cbcl_tile_strided(self._ctx, os.fsencode(path), int(tile), ctypes.c_void_p(filter_dev),
+                                                 int(n_clusters), ctypes.c_void_p(dst), int(well_stride))
         if rc != _lib.OK:
             _raise(self._lib, None, rc, path)
 
-    def load_cbcl_batch(self, entries: Sequence, n_clusters: int, threads: int = 16):
+    def load_cbcl_batch(self, entries: Sequence, n_clusters: int, threads: int = 16, well_stride: int = 1):
         """entries: [(cbcl path, tile number, filter pointer, plane pointer)] - the tiles' blocks are
         inflated on the GPU in one launch and expanded (wd_load_cbcl_batch); the filters must be
         loaded.  Raises what load_cbcl_tile raises for the first entry that fails."""
@@ -310,7 +311,8 @@ class Scanner:
         c_filt = (ctypes.c_void_p * max(1, n))(*[int(e[2]) for e in entries])
         c_dst = (ctypes.c_void_p * max(1, n))(*[int(e[3]) for e in entries])
         rcs = (ctypes.c_int * max(1, n))()
-        rc = self._lib.wd_load_cbcl_batch(self._ctx, n, c_paths, c_tiles, c_filt, c_dst, int(n_clusters), int(threads), rcs)
+        rc = self._lib.wd_load_cbcl_batch_strided(self._ctx, n, c_paths, c_tiles, c_filt, c_dst, int(n_clusters),
+                                                  int(well_stride), int(threads), rcs)
         for i in range(n):
             if rcs[i] != _lib.OK:
                 _raise(self._lib, None, rcs[i], entries[i][0])
