@@ -28,6 +28,7 @@
 #include <mutex>
 #include <thread>
 #include <type_traits>
+#include <utility>
 #include <string>
 #include <vector>
 
