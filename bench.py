@@ -340,6 +340,41 @@ def novaseq_probe(device, n_tiles, levels=7, targets=10000, bases=50):
         except Exception as e:          # noqa: BLE001 - a measurement, not the scan
             sc.set_option("well_stride", 1)
             res["interleaved_by_4"] = {"error": repr(e)}
+        # the lazy gather's worst input on this shape: every read equal (all no-calls), so that no pair dies
+        # early - the line walk (steps finished in place: kLwInPlace) beside the queue kernel on the same tiles
+        try:
+            n_ld = n_tiles                      # (the whole probe: a few tiles do not fill the chip)
+            flat = synth.SynthSpec(seed=4, n_clusters=n, row=cols, nocall_per_64k=65536)
+            low = {"what": "%d tiles, every read equal: each of a target's %.0f neighbours is a duplicate and is read to "
+                           "its last cycle" % (n_ld, P / T)}
+            out3 = sc.malloc(n_ld * ncnt * 8)
+            for stride, key in ((1, "planes"), (4, "interleaved_by_4")):
+                ld = TileBatch(sc, n_ld, bases, n, interleave=stride)
+                ld.fill_synthetic(flat, [(1, int(t)) for t in tile_ids[:n_ld]], list(range(bases)))
+                sc.set_option("well_stride", stride)
+                for name, mode, k in (("equality", MODE_EQ, 0), ("levenshtein_k2", MODE_LEVENSHTEIN, 2)):
+                    for walk, wname in ((1, "line_walk"), (0, "queue_kernel")):
+                        sc.set_option("line_walk", walk)
+                        sc.scan_async(ld.tables, n_ld, bases, n, mode, k, out3)
+                        sc.profile_reset()
+                        for _ in range(3):
+                            sc.scan_async(ld.tables, n_ld, bases, n, mode, k, out3)
+                        w_ms, w_n = sc.profile_get()
+                        low["%s_%s_%s_us_per_tile" % (key, name, wname)] = round(w_ms / max(1, w_n) / n_ld * 1e3, 2)
+                    a_, b_ = low["%s_%s_line_walk_us_per_tile" % (key, name)], low["%s_%s_queue_kernel_us_per_tile" % (key, name)]
+                    low["%s_%s_line_walk_over_queue" % (key, name)] = round(a_ / b_, 3) if b_ else None
+                sc.set_option("well_stride", 1)
+                sc.set_option("line_walk", -1)
+                sc.scan_status()
+                blk3 = sc.d2h(out3, n_ld * ncnt * 8, np.int64).reshape(n_ld, ncnt)
+                low["all_duplicates"] = bool((blk3[:, 1 + levels:1 + 2 * levels] == blk3[:, 1:1 + levels]).all())
+                ld.free()
+            sc.free(out3)
+            res["low_diversity_worst_case"] = low
+        except Exception as e:          # noqa: BLE001 - a measurement, not the scan
+            sc.set_option("well_stride", 1)
+            sc.set_option("line_walk", -1)
+            res["low_diversity_worst_case"] = {"error": repr(e)}
         # the .cbcl side of this config: 8 tiles x `bases` cycles as NovaSeq writes them (one file per
         # cycle and surface, one gzip block per tile: 2 wells per byte, 2 quality bits, excluded wells
         # left out), through the GPU decoder (wd_load_cbcl_batch) and through the host loader

@@ -302,6 +302,9 @@ def test_low_diversity_stress(sc, kind):
         sc.set_targets(centre, lvl_off, nbr)
         tb = TileBatch(sc, 2, L, spec.n_clusters)
         tb.fill_synthetic(spec, [(1, 1101), (2, 1102)], list(range(L)))
+        slots_max = int((lvl_off[:, -1] - lvl_off[:, 0]).max())
+        il = TileBatch(sc, 2, L, spec.n_clusters, interleave=4)
+        il.fill_synthetic(spec, [(1, 1101), (2, 1102)], list(range(L)))
         for mode, k in ((0, 0), (1, 1), (1, 3), (2, 2)):
             res = {}
             for q in (0, 1):
@@ -309,6 +312,25 @@ def test_low_diversity_stress(sc, kind):
                 res[q] = tb.count(mode, k, per_target=True)
             sc.set_option("queue_kernel", 1)
             assert (res[0][0] == res[1][0]).all() and (res[0][1] == res[1][1]).all()
+            # the line walk on the same input, both layouts: steps whose pairs nearly all survive the first
+            # round are finished in place (kLwInPlace), the rest through the queue and its drains
+            try:
+                sc.set_option("line_walk", 1)
+                for pairs in (0, 300):
+                    sc.set_option("line_pairs", pairs)
+                    for batch in (tb, il):
+                        if batch is il and mode == 2 and k > 3:
+                            continue
+                        got = batch.count(mode, k, per_target=True)
+                        assert sc.last_kernel().startswith("k_scan_lines"), sc.last_kernel()
+                        assert (got[0] == res[1][0]).all() and (got[1] == res[1][1]).all(), (kind, ring, mode, k, pairs)
+                sc.set_option("line_walk", 0)
+                if slots_max <= 508:
+                    got = il.count(mode, k, per_target=True)           # k_scan_q on the interleaved layout
+                    assert (got[0] == res[1][0]).all() and (got[1] == res[1][1]).all(), (kind, ring, mode, k)
+            finally:
+                sc.set_option("line_walk", -1)
+                sc.set_option("line_pairs", 0)
             for i, (lane, tile) in enumerate([(1, 1101), (2, 1102)]):
                 planes, filt, c2, n2, _ = compact_tile(spec, lane, tile, list(range(L)), centre, nbr)
                 valid, dups, lens, _ = oracle.count_tile(planes, filt, c2, lvl_off, n2, mode, k)
@@ -320,6 +342,7 @@ def test_low_diversity_stress(sc, kind):
             if kind == "all_nocall" and mode == 0:
                 assert res[1][0][:, 1 + levels:1 + 2 * levels].sum() == res[1][0][:, 1:1 + levels].sum()  # all dups
         tb.free()
+        il.free()
 
 
 def _mutate(rng, seq, n_edits):
