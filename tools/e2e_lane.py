@@ -90,7 +90,9 @@ try:
         t1 = time.perf_counter()
         err = io.StringIO()
         with redirect_stdout(buf), redirect_stderr(err):
-            cwd.main(argv + extra)
+            # WD_LANE_EXITING=1: as `python -m well_duplicates_amd.count_well_duplicates` closes its context - the
+            # process ends next, nothing is freed one by one ("fast_exit"; this tool then leaks a run's buffers)
+            cwd.main(argv + extra, exiting=bool(os.environ.get("WD_LANE_EXITING")))
         for line in err.getvalue().splitlines():
             if line.startswith("[wd "):            # WD_CLI_TIMING / WD_INFLATE_STATS lines, not the duplicate log
                 print(line)
