@@ -64,6 +64,7 @@ inline uint32_t wv_shfl_up(uint32_t v, int d)
 inline uint32_t wv_uniform(uint32_t v) { return wv_shfl(v, 0); }
 inline uint32_t wv_readlane(uint32_t v, uint32_t src) { return wv_shfl(v, (int)src); }
 inline void wv_sync() { bar(); }
+#define WV_GLOBAL                        /* (the GPU build: address_space(1)) */
 inline uint32_t wv_hist_byte(const uint8_t *p) { return *p; }
 inline void wv_stores_done() {}
 inline unsigned long long wv_clock() { return 0; }
