@@ -70,3 +70,35 @@ def test_mode_selection():
     assert compare_mode(0, False) == (MODE_EQ, 0) and compare_mode(0, True) == (MODE_EQ, 0)
     assert compare_mode(2, True) == (MODE_HAMMING, 2)
     assert compare_mode(2, False) == (MODE_LEVENSHTEIN, 2)
+
+
+def test_resident_layout_choice():
+    """--layout auto: the interleaved-by-four layout wherever the kernels that read it serve the run - sampled
+    targets of at most 508 neighbour slots, equality / Hamming <= 254 / Levenshtein <= 3 (the reference's default
+    is -e 2, count_well_duplicates.py:282-283), fewer than 65 536 targets - and planes for everything else."""
+    import numpy as np
+    from well_duplicates_amd.scanner import compare_mode
+
+    def csr(T, per_target):
+        off = (np.arange(T)[:, None] * per_target + np.array([0, per_target // 2, per_target])[None, :]).astype(np.int32)
+        return np.arange(T, dtype=np.int32), off, np.zeros(T * per_target, dtype=np.int32)
+
+    def layout(argv, c, cycles=(0, 1, 2, 3)):
+        args = cwd.parse_args(["-s", "hiseq_x", "-r", "/nowhere"] + argv)
+        mode, k = compare_mode(args.edit_distance, args.hamming)
+        return cwd.resident_layout(args, mode, k, c, None, [1], ["1101"], list(cycles))
+
+    small = csr(100, 86)
+    assert layout(["-f", "x"], small) == 4                                   # the reference's defaults: -e 2, Levenshtein
+    assert layout(["-f", "x", "-e", "0"], small) == 4
+    assert layout(["-f", "x", "-e", "3"], small) == 4
+    assert layout(["-f", "x", "-e", "4"], small) == 1                        # wider bands read planes
+    assert layout(["-f", "x", "-e", "200", "--hamming"], small) == 4
+    assert layout(["-f", "x", "-e", "255", "--hamming"], small) == 1         # beyond the 8-bit mismatch count
+    assert layout(["-f", "x"], csr(100, 600)) == 1                           # more slots than four passes hold
+    assert layout(["-f", "x"], csr(70000, 4)) == 1                           # 65 536 targets: the dense path, on planes
+    assert layout(["--all-wells"], None) == 1
+    assert layout(["-f", "x", "--layout", "planes"], small) == 1
+    assert layout(["-f", "x", "--layout", "interleaved"], small) == 4
+    with pytest.raises(SystemExit):                                          # the explicit layout is checked at once
+        cwd.parse_args(["-s", "hiseq_x", "-r", "/nowhere", "-f", "x", "-e", "5", "--layout", "interleaved"])
