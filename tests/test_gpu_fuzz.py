@@ -71,6 +71,9 @@ def test_fuzz(seed):
         sc.set_targets(centre, lvl_off, nbr)
         tb = TileBatch(sc, len(tiles), L, n)
         tb.fill_synthetic(spec, tiles, cycles)
+        il = TileBatch(sc, len(tiles), L, n, interleave=4)          # the layout the CLI keeps resident where it is served
+        il.fill_synthetic(spec, tiles, cycles)
+        slots_max = int((lvl_off[:, -1] - lvl_off[:, 0]).max())
         host = [compact_tile(spec, lane, tile, cycles, centre, nbr) for lane, tile in tiles]
         modes = [(0, 0), (1, int(rng.integers(0, 5))), (1, int(rng.integers(-1, L + 2))),
                  (2, 2), (2, int(rng.integers(2, 8))), (2, int(rng.integers(8, 30)))]
@@ -109,7 +112,22 @@ def test_fuzz(seed):
                     got[got == INVALID_TARGET] = -1
                     assert (got == want[i][0]).all(), (seed, mode, k, opts, i)
                     assert (blocks_to_reference(blocks[i], levels) == want[i][1]).all(), (seed, mode, k, opts)
+                # the same trial on the interleaved batch, where the kernels that read it serve the mode
+                # (k_scan_q<.., 4>: targets of at most 508 slots; k_scan_lines<.., 4> when the walk is on and applies)
+                served = mode == 0 or (mode == 1 and k <= 254) or (mode == 2 and k <= 3)
+                if served and opts["queue_kernel"] and opts["early_exit"] and opts["dense_kernel"] != 1:
+                    try:
+                        blocks, pt = il.count(mode, k, per_target=True)
+                    except RuntimeError as e:       # the one documented refusal: nobody reads this layout for these targets
+                        assert "interleaved layout" in str(e) and slots_max > 508, (seed, mode, k, opts, str(e))
+                        continue
+                    for i in range(len(tiles)):
+                        got = pt[i].astype(np.int64)
+                        got[got == INVALID_TARGET] = -1
+                        assert (got == want[i][0]).all(), ("interleaved", seed, mode, k, opts, i, sc.last_kernel())
+                        assert (blocks_to_reference(blocks[i], levels) == want[i][1]).all(), ("interleaved", seed, mode, k, opts)
         tb.free()
+        il.free()
 
 
 # ---- the dense path's window groups -------------------------------------------------------
