@@ -373,11 +373,7 @@ int launch_dense(wd_ctx *ctx, const ScanArgs &a, int n_tiles, int64_t N, bool st
         d.bprefix = d.mark + 2 * (size_t)nt * d.mw_stride;
         d.cand = ctx->d_cand + cand_words * set;
         d.rows = want_rows ? ctx->d_rows + (size_t)part * (size_t)N * kRowGroups * set : nullptr;
-        WD_HIP(ctx, hipMemsetAsync(d.cand, 0, (kDenseSlots + 1) * sizeof(uint32_t), st));
-        WD_HIP(ctx, hipMemsetAsync(d.partial, 0, (size_t)nt * kDenseSlots * d.partial_stride * sizeof(unsigned long long), st));
-        WD_HIP(ctx, hipMemsetAsync(d.mask, 0, (size_t)nt * d.mask_stride * sizeof(uint32_t), st));
-        if (d.rows)
-            WD_HIP(ctx, hipMemsetAsync(d.mark, 0, (size_t)nt * d.mw_stride * sizeof(uint32_t), st));
+        // (k_dense_sig clears the part's scratch: dense_clear_scratch)
         const dim3 grid((unsigned)((long long)kXcds * ((dense_bpt + kXcds - 1) / kXcds) * ((nt + tc - 1) / tc)));
         const dim3 grid4((unsigned)((N + 4ll * kBlock - 1) / (4ll * kBlock)), (unsigned)nt);
         const dim3 grid1((unsigned)((N + kBlock - 1) / kBlock), (unsigned)nt);
