@@ -85,6 +85,8 @@ def parse(argv=None):
     ap.add_argument("--dense-tiles", type=int, default=8,
                     help="tiles of the all-centres probe (BASELINE configs[4] shape: every well a centre, "
                          "3 levels, 150 bp) reported under other_modes; 0 = skip")
+    ap.add_argument("--dense-tiles-large", type=int, default=32,
+                    help="a second all-centres probe on this many tiles (equality and Levenshtein <= 2); 0 = skip")
     ap.add_argument("--option", action="append", default=[], help="name=value scanner option")
     ap.add_argument("--merge-every", type=int, default=0,
                     help="steps merged by one all-reduce (N > 1); 0 = one merge per job (all timed steps)")
@@ -203,7 +205,7 @@ def with_traffic(res, key, tiles, ms, kernel):
     return res
 
 
-def dense_probe(device, n_tiles, rows, cols, levels=3, bases=150):
+def dense_probe(device, n_tiles, rows, cols, levels=3, bases=150, modes=("levenshtein_k2", "hamming_k2", "equality")):
     """Kernel time of the dense path (scan_dense.inc) on n_tiles full-size tiles."""
     import numpy as np
     from well_duplicates_amd import synth
@@ -233,6 +235,8 @@ def dense_probe(device, n_tiles, rows, cols, levels=3, bases=150):
         # the reference's default metric (Levenshtein <= 2), Hamming <= 2, then equality for the counters
         for name, mode, k, case in (("levenshtein_k2", MODE_LEVENSHTEIN, 2, "dense_lev2"),
                                     ("hamming_k2", MODE_HAMMING, 2, "dense_ham2"), ("equality", MODE_EQ, 0, "dense_eq")):
+            if name not in modes:
+                continue
             sc.scan_async(tb.tables, n_tiles, bases, n, mode, k, out)
             sc.profile_reset()
             for _ in range(4):
@@ -955,6 +959,11 @@ def main(argv=None):
     # 3 levels), 150 bp, 2 % planted duplicates as in SURVEY.md 8d; its own context and planes
     if rank == 0 and world == 1 and args.dense_tiles > 0 and args.profile_steps > 0 and args.mode == "eq":
         other["dense_all_centres"] = dense_probe(local_rank, args.dense_tiles, rows, cols)
+        if args.dense_tiles_large > args.dense_tiles:
+            # the same chain over a third of a lane: every kernel of it is a bigger launch, its ramp and tail a
+            # smaller share (the per-tile figure of a real scan - a lane is 96 or 112 tiles - is this one)
+            other["dense_all_centres"]["at_%d_tiles" % args.dense_tiles_large] = dense_probe(
+                local_rank, args.dense_tiles_large, rows, cols, modes=("levenshtein_k2", "equality"))
     if rank == 0 and world == 1 and args.novaseq_tiles > 0 and args.profile_steps > 0 and args.mode == "eq":
         other["novaseq_cfg4"] = novaseq_probe(local_rank, args.novaseq_tiles)
     b_alg = compares_rank * (L + 4) + valid_rank * (L + 5) + 8 * ncnt * args.tiles

@@ -91,7 +91,7 @@ int wd_synchronize(wd_ctx *ctx);
 /* Tunables, by name (default): "early_exit" (1), "targets_per_block" (64), "queue_kernel" (1),
  * "queue_first" (0 = from k), "batch_first" (4), "batch_next" (4), "profile" (0),
  * "null_stream" (0), "dense_kernel" (-1 = automatic: lane-per-target kernel when T >= 65536),
- * "dense_tile_chunk" (8: tiles one wave takes a group of 64 targets through in the dense path),
+ * "dense_tile_chunk" (16: tiles one wave takes a group of 64 targets through in the dense path),
  * "dense_queue_cap" (0 = 16, 32 for Levenshtein: survivor entries per 64 targets, at most 64), "dense_pack" (-1 = settle the
  * survivors on packed rows of the wells they involve whenever there are any, 0 = byte by byte on
  * the planes, 1 = rows always), "dense_windows" (1: groups of consecutive centres compare their

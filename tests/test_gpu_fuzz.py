@@ -235,7 +235,7 @@ def test_fuzz_window_groups(seed):
                 for trial in range(3):
                     opts = {"dense_kernel": 1,
                             "dense_windows": int(rng.integers(0, 2)) if trial else 1,
-                            "dense_tile_chunk": int(rng.choice([1, 2, 3, 8])),
+                            "dense_tile_chunk": int(rng.choice([1, 2, 3, 8, 16])),
                             "dense_queue_cap": int(rng.choice([0, 0, 1, 3, 64])),
                             "dense_pack": int(rng.choice([-1, 0, 1])) if trial else -1,
                             "dense_overlap": int(rng.integers(0, 2)) if trial else 0,

@@ -21,7 +21,7 @@ struct wd_ctx {
     int queue_kernel = 1;      // equality / Hamming with early exit: use k_scan_q
     int queue_first = 0;       // cycles of its first round; 0 = choose from k
     int dense_kernel = -1;     // lane-per-target kernel: -1 = when the targets look dense
-    int dense_tile_chunk = 8;  // dense kernel: tiles a group of targets is taken through by one wave
+    int dense_tile_chunk = 16; // dense kernel: tiles a group of targets is taken through by one wave
     uint32_t *d_sig = nullptr; // dense path: signature planes [n_tiles][sig_stride]
     size_t sig_cap = 0;        // elements
     unsigned long long *d_partial = nullptr;   // dense path: counter slots [n_tiles][kDenseSlots][stride]
