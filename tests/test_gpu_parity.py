@@ -639,6 +639,51 @@ def test_dense_window_groups(sc, L, sym):
         tb.free()
 
 
+@pytest.mark.parametrize("sym", [1, 0])
+def test_dense_tiles_per_wave(sc, sym):
+    """`dense_tile_chunk` - the tiles a wave of the compare stage takes one group of targets through, 16 by
+    default - against a scan of 19 tiles: a full chunk and a ragged one (16 + 3), and the same tiles in
+    chunks of 1, 5 and 8.  Every mode; tiles 0, 15, 16 and 18 (the chunks' ends) against the oracle, all
+    19 rows and per-target counts equal whatever the chunk."""
+    from well_duplicates_amd import workload
+    rows, cols, levels, L = 12, 200, 3, 40
+    n = rows * cols
+    x, y = synth.honeycomb_pixels(rows, cols)
+    centre, lvl_off, nbr = workload.targets_to_csr(cluster_indexes.generate(x, y, range(n), levels))
+    spec = synth.SynthSpec(seed=77, n_clusters=n, row=cols, plant_per_64k=4000, plant_far=True, nocall_per_64k=900,
+                           pass_per_64k=50000)
+    sc.set_option("dense_sym", sym)
+    sc.set_targets(centre, lvl_off, nbr)
+    tiles = [(1 + i % 4, 1101 + i) for i in range(19)]
+    tb = TileBatch(sc, len(tiles), L, n)
+    tb.fill_synthetic(spec, tiles, list(range(L)))
+    try:
+        sc.set_option("dense_kernel", 1)
+        assert sc.get_option("dense_tile_chunk") == 16
+        for mode, k in ((0, 0), (1, 2), (2, 2)):
+            blocks, pt = tb.count(mode, k, per_target=True)
+            assert sc.get_option("dense_window_groups") > 0 and sc.get_option("dense_sym_on") == sym
+            for i in (0, 15, 16, 18):
+                lane, tile = tiles[i]
+                planes = [synth.plane_bytes(spec, lane, tile, c) for c in range(L)]
+                valid, dups, lens, _ = oracle.count_tile(planes, synth.filter_bytes(spec, lane, tile), centre, lvl_off, nbr, mode, k)
+                got = pt[i].astype(np.int64)
+                got[got == INVALID_TARGET] = -1
+                assert (got == np.where(valid[:, None] == 1, dups, -1)).all(), (mode, k, i)
+                assert (blocks_to_reference(blocks[i], levels) == oracle.tally_tile(valid, dups, lens)).all(), (mode, k, i)
+            assert int(blocks[:, 1 + levels:1 + 2 * levels].sum()) > 0
+            for chunk in (1, 5, 8):
+                sc.set_option("dense_tile_chunk", chunk)
+                b2, p2 = tb.count(mode, k, per_target=True)
+                sc.set_option("dense_tile_chunk", 16)
+                assert (b2 == blocks).all() and (p2 == pt).all(), (mode, k, chunk)
+    finally:
+        sc.set_option("dense_kernel", -1)
+        sc.set_option("dense_tile_chunk", 16)
+        sc.set_option("dense_sym", 1)
+        tb.free()
+
+
 @pytest.mark.parametrize("L", [1, 3, 5, 6, 9])
 def test_dense_short_reads(sc, L):
     """Reads no longer than the 5-cycle signature never reach the verify kernel; low diversity
