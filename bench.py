@@ -231,7 +231,10 @@ def dense_probe(device, n_tiles, rows, cols, levels=3, bases=150, modes=("levens
                "algorithmic_bytes": int(b_dense), "ring_generator_s": round(gen_s, 3),
                "window_groups": sc.get_option("dense_window_groups"), "groups": (T + 63) // 64,
                # 1: the neighbour relation is symmetric, every pair is compared from its lower well only
-               "pairs_from_one_end": sc.get_option("dense_sym_on")}
+               "pairs_from_one_end": sc.get_option("dense_sym_on"),
+               # this box's rate for a kernel that only reads (roofline.stream_read): k_dense_pack and k_dense_sig
+               # stream 150 planes per tile, 0.8 of the chain's time
+               "stream_read_gbs": round(sc.stream_read_gbs(tb.d_planes, tb.plane_bytes - tb.plane_bytes % 16, passes=3), 1)}
         # the reference's default metric (Levenshtein <= 2), Hamming <= 2, then equality for the counters
         for name, mode, k, case in (("levenshtein_k2", MODE_LEVENSHTEIN, 2, "dense_lev2"),
                                     ("hamming_k2", MODE_HAMMING, 2, "dense_ham2"), ("equality", MODE_EQ, 0, "dense_eq")):
@@ -968,6 +971,16 @@ def main(argv=None):
         other["novaseq_cfg4"] = novaseq_probe(local_rank, args.novaseq_tiles)
     b_alg = compares_rank * (L + 4) + valid_rank * (L + 5) + 8 * ncnt * args.tiles
     achieved = b_alg / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0
+    # what THIS box's HBM gives a kernel that only reads (the boxes of a pool differ by several percent): the
+    # resident lane's planes read once per pass by k_stream_read, nothing computed
+    stream_read = None
+    if rank == 0 and args.profile_steps > 0 and tb.plane_bytes >= (1 << 28):
+        gbs = sc.stream_read_gbs(tb.d_planes, tb.plane_bytes - tb.plane_bytes % 16, passes=5)
+        stream_read = {"gbs": round(gbs, 1), "bytes_per_pass": tb.plane_bytes - tb.plane_bytes % 16, "passes": 5,
+                       "achieved_over_stream_read": round(achieved / gbs, 4) if gbs > 0 else None,
+                       "what": "wd_stream_read_probe: the timed lane's resident planes read once per pass, 16 bytes per "
+                               "lane and load, non-temporal, nothing computed - the rate a scan kernel's lines could "
+                               "arrive at on this box (the guide's figure for a copy: %.0f GB/s)" % (ACHIEVABLE_HBM_FRAC * HBM_PEAK_GBS)}
     case = {"eq": "eq", "hamming": "ham%d" % k, "levenshtein": "lev%d" % k}[args.mode]
     if args.no_early_exit:
         case = "full"
@@ -983,6 +996,7 @@ def main(argv=None):
                 "traffic_is": "L2-miss bytes per launch (2 x FETCH_SIZE + WRITE_SIZE of the PMC passes): an upper bound of "
                               "the HBM bytes, the Infinity Cache sits behind the L2",
                 "two_lanes_alternating": two_lanes,
+                "stream_read": stream_read,
                 "algorithmic_bytes_per_launch": b_alg,
                 "kernel_ms": round(kern_ms, 5), "launches_timed": launches,
                 "region_ms_per_launch": round(region_ms, 5),

@@ -325,6 +325,11 @@ int wd_hitlog_fetch(wd_ctx *ctx, wd_hit *out_host, int64_t max_records, int64_t 
  * around every n-th scan call): total milliseconds and timed launches since the last reset. */
 int wd_profile_get(wd_ctx *ctx, double *total_ms, int64_t *launches);
 int wd_profile_reset(wd_ctx *ctx);
+/* What this GPU's memory gives a kernel that only reads: `passes` passes over `bytes` of device memory
+ * (16-byte aligned; 16 bytes per lane and load, non-temporal), timed with HIP events on the context's stream;
+ * *ms_per_pass = the mean.  Measurement aid (bench.py quotes the scan kernels' rates beside it); the
+ * reference has nothing like it. */
+int wd_stream_read_probe(wd_ctx *ctx, const void *src_dev, size_t bytes, int passes, double *ms_per_pass);
 /* Template name of the compare kernel the last scan launched, as the code object spells it
  * (e.g. "k_scan_q<true, 2, 0, 1>"; "" before the first scan): ties a counter profile of a kernel
  * to the kernel a measurement really ran.  The string lives in the context. */

@@ -988,6 +988,25 @@ def test_count_tiles_accepts_host_memory(sc):
         tb.free()
 
 
+def test_stream_read_probe(sc):
+    """wd_stream_read_probe: a plausible rate for a kernel that only reads (between a PCIe link's and the HBM's
+    nominal 8 TB/s), whatever the buffer's length modulo the unrolled step; bad arguments refused."""
+    for nbytes in (1 << 28, (1 << 26) + 16 * 12345, 4096, 16):
+        buf = sc.malloc(nbytes)
+        try:
+            sc.memset(buf, 7, nbytes)
+            gbs = sc.stream_read_gbs(buf, nbytes, passes=3)
+            assert gbs > 0
+            if nbytes >= (1 << 28):
+                assert 500.0 < gbs < 8000.0, gbs
+            with pytest.raises(ValueError):
+                sc.stream_read_gbs(buf + 4, nbytes - 16 if nbytes > 16 else 16)          # not 16-byte aligned
+            with pytest.raises(ValueError):
+                sc.stream_read_gbs(buf, nbytes, passes=0)
+        finally:
+            sc.free(buf)
+
+
 def test_fresh_context_requires_targets():
     s = Scanner(0)
     with pytest.raises(RuntimeError):

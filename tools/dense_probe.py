@@ -31,6 +31,7 @@ spec = synth.SynthSpec(seed=5, n_clusters=n, row=a.cols, plant_per_64k=a.plant)
 tb = TileBatch(sc, a.tiles, a.bases, n)
 tb.fill_synthetic(spec, [(1, 1101 + i) for i in range(a.tiles)], list(range(a.bases)))
 out = sc.malloc(a.tiles * (1 + 5 * a.levels) * 8)
+print("stream read of the resident planes: %.0f GB/s" % sc.stream_read_gbs(tb.d_planes, tb.plane_bytes - tb.plane_bytes % 16, 3))
 sc.set_option("profile", 1)
 sc.set_option("dense_pack", a.pack)
 for ch in [int(v) for v in a.chunk.split(",")] * 2:

@@ -4,7 +4,7 @@
 cd /tmp && export TMPDIR=/tmp; R=${GRAFT_REPO_ROOT:-/root/repo}; SYM=${1:-1}; TILES=${2:-8}
 for cfg in ${MODES:-0:0 2:2}; do set -- ${cfg/:/ }
 rm -rf /tmp/prof_$1; rocprofv3 --kernel-trace --stats -d /tmp/prof_$1 -o run --output-format csv -- python3 $R/tools/dense_probe.py --tiles $TILES --mode $1 -k $2 --chunk 8 --sym $SYM --plant ${PLANT:-1311} > /tmp/probe_$1.log 2>&1
-f=$(find /tmp/prof_$1 -name "*kernel_stats.csv" | head -1); echo "== mode $1 sym $SYM"; grep "^scan" /tmp/probe_$1.log | tail -1
+f=$(find /tmp/prof_$1 -name "*kernel_stats.csv" | head -1); echo "== mode $1 sym $SYM"; grep "^stream" /tmp/probe_$1.log | tail -1; grep "^scan" /tmp/probe_$1.log | tail -1
 python3 - "$f" <<'PY'
 import csv, sys, re
 for r in csv.DictReader(open(sys.argv[1])):

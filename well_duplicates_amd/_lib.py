@@ -89,6 +89,7 @@ PROTOTYPES = {
     "wd_hitlog_fetch": (_i, [_vp, _vp, _i64, ctypes.POINTER(_i64)]),
     "wd_profile_get": (_i, [_vp, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(_i64)]),
     "wd_profile_reset": (_i, [_vp]),
+    "wd_stream_read_probe": (_i, [_vp, _vp, ctypes.c_size_t, _i, ctypes.POINTER(ctypes.c_double)]),
     "wd_last_kernel": (ctypes.c_char_p, [_vp]),
     "wd_comm_unique_id": (_i, [_vp]),
     "wd_comm_init": (_i, [_vp, _i, _i, _vp]),

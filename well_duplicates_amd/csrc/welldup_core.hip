@@ -613,6 +613,63 @@ int wd_profile_reset(wd_ctx *ctx)
     return WD_OK;
 }
 
+// ---- what this GPU streams ------------------------------------------------------------
+// A read of `bytes` of device memory and nothing else: 16 bytes per lane and load, eight loads in flight per
+// thread, non-temporal, one word written per workgroup whose bytes XOR to something (so the loads stay).
+// The rate is what the HBM of THIS box gives a kernel that does no work - the boxes of a pool differ by
+// several percent, and a roofline fraction is read against it (bench.py: roofline.stream_read).
+__global__ __launch_bounds__(kBlock) void k_stream_read(const uint4 *src, size_t n16, uint32_t *sink)
+{
+    typedef uint32_t U4 __attribute__((ext_vector_type(4)));
+    const __attribute__((address_space(1))) U4 *p = (const __attribute__((address_space(1))) U4 *)src;
+    U4 acc = {0u, 0u, 0u, 0u};
+    const size_t step = (size_t)gridDim.x * kBlock;
+    size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
+    for (; i + 7 * step < n16; i += 8 * step) {
+        U4 v[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++)
+            v[j] = __builtin_nontemporal_load(p + i + j * step);
+#pragma unroll
+        for (int j = 0; j < 8; j++)
+            acc ^= v[j];
+    }
+    for (; i < n16; i += step)
+        acc ^= __builtin_nontemporal_load(p + i);
+    const uint32_t x = acc.x ^ acc.y ^ acc.z ^ acc.w;
+    if (x == 0x9E3779B9u)                            // (never, for all that matters: the sink is there to be written to)
+        sink[blockIdx.x & 63] = x;
+}
+
+int wd_stream_read_probe(wd_ctx *ctx, const void *src_dev, size_t bytes, int passes, double *ms_per_pass)
+try {
+    if (!ctx || !src_dev || !ms_per_pass || passes < 1 || bytes < 16 || ((uintptr_t)src_dev & 15u))
+        return fail(ctx, WD_ERR_ARG, "wd_stream_read_probe: a 16-byte aligned device buffer, passes >= 1");
+    if (bind_device(ctx))
+        return WD_ERR_HIP;
+    uint32_t *sink = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    WD_HIP(ctx, hipMalloc((void **)&sink, 64 * sizeof(uint32_t)));
+    WD_HIP(ctx, hipEventCreate(&e0));
+    WD_HIP(ctx, hipEventCreate(&e1));
+    const size_t n16 = bytes / 16;
+    // (workgroups: enough for every CU's wave slots several times over, few enough that each streams megabytes)
+    const unsigned grid = (unsigned)std::min<size_t>(std::max<size_t>(1, n16 / (8 * kBlock)), 256 * 64);
+    hipLaunchKernelGGL(k_stream_read, dim3(grid), dim3(kBlock), 0, ctx->stream, (const uint4 *)src_dev, n16, sink);   // warm-up
+    WD_HIP(ctx, hipEventRecord(e0, ctx->stream));
+    for (int r = 0; r < passes; r++)
+        hipLaunchKernelGGL(k_stream_read, dim3(grid), dim3(kBlock), 0, ctx->stream, (const uint4 *)src_dev, n16, sink);
+    WD_HIP(ctx, hipEventRecord(e1, ctx->stream));
+    WD_HIP(ctx, hipEventSynchronize(e1));
+    float ms = 0.f;
+    WD_HIP(ctx, hipEventElapsedTime(&ms, e0, e1));
+    *ms_per_pass = (double)ms / passes;
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    (void)hipFree(sink);
+    return WD_OK;
+} WD_CATCH
+
 // ---- RCCL ----------------------------------------------------------------------------
 int wd_comm_unique_id(void *out128)
 {

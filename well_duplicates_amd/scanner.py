@@ -365,6 +365,13 @@ class Scanner:
     def profile_reset(self):
         self._ck(self._lib.wd_profile_reset(self._ctx))
 
+    def stream_read_gbs(self, dev_ptr: int, nbytes: int, passes: int = 5) -> float:
+        """GB/s of a kernel that only reads `nbytes` of device memory (wd_stream_read_probe): what this box's
+        HBM gives a stream - the yardstick beside a scan kernel's rate."""
+        ms = ctypes.c_double()
+        self._ck(self._lib.wd_stream_read_probe(self._ctx, ctypes.c_void_p(dev_ptr), nbytes, passes, ctypes.byref(ms)))
+        return nbytes / (ms.value * 1e-3) / 1e9
+
     def last_kernel(self) -> str:
         """Template name of the compare kernel the last scan launched (wd_last_kernel)."""
         return self._lib.wd_last_kernel(self._ctx).decode()
