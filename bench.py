@@ -85,8 +85,8 @@ def parse(argv=None):
     ap.add_argument("--dense-tiles", type=int, default=8,
                     help="tiles of the all-centres probe (BASELINE configs[4] shape: every well a centre, "
                          "3 levels, 150 bp) reported under other_modes; 0 = skip")
-    ap.add_argument("--dense-tiles-large", type=int, default=32,
-                    help="a second all-centres probe on this many tiles (equality and Levenshtein <= 2); 0 = skip")
+    ap.add_argument("--dense-tiles-large", type=int, default=96,
+                    help="a second all-centres probe on this many tiles - a lane (equality and Levenshtein <= 2); 0 = skip")
     ap.add_argument("--option", action="append", default=[], help="name=value scanner option")
     ap.add_argument("--merge-every", type=int, default=0,
                     help="steps merged by one all-reduce (N > 1); 0 = one merge per job (all timed steps)")
@@ -963,8 +963,8 @@ def main(argv=None):
     if rank == 0 and world == 1 and args.dense_tiles > 0 and args.profile_steps > 0 and args.mode == "eq":
         other["dense_all_centres"] = dense_probe(local_rank, args.dense_tiles, rows, cols)
         if args.dense_tiles_large > args.dense_tiles:
-            # the same chain over a third of a lane: every kernel of it is a bigger launch, its ramp and tail a
-            # smaller share (the per-tile figure of a real scan - a lane is 96 or 112 tiles - is this one)
+            # the same chain over a whole lane (62 GB of planes resident): every kernel of it is a bigger launch, its
+            # ramp and tail a smaller share - the per-tile figure of a real scan is this one
             other["dense_all_centres"]["at_%d_tiles" % args.dense_tiles_large] = dense_probe(
                 local_rank, args.dense_tiles_large, rows, cols, modes=("levenshtein_k2", "equality"))
     if rank == 0 and world == 1 and args.novaseq_tiles > 0 and args.profile_steps > 0 and args.mode == "eq":
